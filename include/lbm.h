@@ -1,0 +1,146 @@
+/* lbm.h -- C ABI of liblbm_hip.so: MI355X-native D2Q9 lid-driven-cavity lattice-Boltzmann hot path.
+ *
+ * Drop-in boundary for the PyCUDA usage of the reference's GPU script.  Each entry point
+ * cites the reference interface it replaces (paths relative to the reference repo root).
+ * Plain C types only: no torch / C++ types cross this boundary.  Every function returning
+ * int returns LBM_OK (0) or a negative lbm_status; the text is available from
+ * lbm_last_error().  No C++ exception crosses the ABI.  One host thread per context.
+ *
+ * Host array convention (same as the reference scripts): fin[9][X][Y], u[2][X][Y],
+ * rho[X][Y], C order, y fastest, y = 0 is the moving lid (MRT.py:192-209,
+ * MRT_GPU.py:207-229).  On the device the library keeps one padded plane per direction,
+ * x fastest (the transposition the reference does on the host at MRT_GPU.py:283-289 and
+ * MRT_GPU.py:758-760 is done inside lbm_set_state / lbm_get_fields).
+ */
+#ifndef LBM_H
+#define LBM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_ABI_VERSION 1
+
+typedef enum lbm_status {
+    LBM_OK = 0,
+    LBM_ERR_INVALID = -1, /* bad argument / unsupported combination */
+    LBM_ERR_HIP = -2,     /* a HIP runtime call failed (text in lbm_last_error) */
+    LBM_ERR_NOMEM = -3,
+    LBM_ERR_STATE = -4,   /* call not valid in the current context state */
+    LBM_ERR_COMM = -5     /* RCCL failure */
+} lbm_status;
+
+enum { LBM_F32 = 0, LBM_F64 = 1 };                      /* storage and arithmetic type */
+enum { LBM_SRT = 0, LBM_TRT = 1, LBM_MRT = 2 };         /* RT = 'SRT' | 'TRT' | 'MRT'  (MRT_GPU.py:48) */
+enum { LBM_SEM_MRT_PY = 0, LBM_SEM_MRT_GPU = 1 };       /* streaming windows + wall rules of MRT.py:404-453
+                                                           or of MRT_GPU.py:412,674-692 */
+enum { LBM_KERNEL_AUTO = 0, LBM_KERNEL_GENERIC = 1, LBM_KERNEL_VEC = 2 }; /* fused pull kernel variant */
+enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour towards smaller / larger y */
+
+/* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
+ * reference bakes them into the CUDA source by '%'-formatting (MRT_GPU.py:422,531,662) and
+ * recompiles per parameter set; here the code object is compiled ahead of time for gfx950. */
+typedef struct lbm_params {
+    int32_t struct_size; /* = sizeof(lbm_params) */
+    int32_t nx;          /* xsize */
+    int32_t ny;          /* ysize of the WHOLE lattice */
+    int32_t y0;          /* first global row owned by this context (0 when not slab-decomposed) */
+    int32_t ny_local;    /* rows owned by this context (= ny when not slab-decomposed, >= 2) */
+    int32_t dtype;       /* LBM_F32 | LBM_F64 */
+    int32_t collision;   /* LBM_SRT | LBM_TRT | LBM_MRT */
+    int32_t semantics;   /* LBM_SEM_MRT_PY | LBM_SEM_MRT_GPU */
+    int32_t kernel;      /* LBM_KERNEL_* */
+    int32_t turb;        /* must be 0 (Smagorinsky closure, MRT_GPU.py:368-387, not built yet) */
+    int32_t device;      /* HIP device ordinal (reference: cuda.Device(0), MRT_GPU.py:29) */
+    int32_t reserved;
+    double uLB;          /* lid velocity, MRT_GPU.py:57 */
+    double omega;        /* = omegap = omega_nu, MRT_GPU.py:65 */
+    double omegam;       /* TRT, MRT_GPU.py:80 */
+    double omega_e;      /* MRT, MRT_GPU.py:89 */
+    double omega_eps;    /* MRT, MRT_GPU.py:90 */
+    double omega_q;      /* MRT, MRT_GPU.py:90 */
+} lbm_params;
+
+typedef struct lbm_ctx lbm_ctx;
+
+/* --- library ----------------------------------------------------------------------- */
+int lbm_abi_version(void);
+/* replaces: pycuda.autoinit device discovery (MRT_GPU.py:23-30) */
+int lbm_device_count(void);
+
+/* --- context ----------------------------------------------------------------------- */
+/* replaces: import pycuda.autoinit + cuda.mem_alloc x8 + SourceModule/get_function
+ * (MRT_GPU.py:23-30,309-316,701-703).  Returns NULL on failure with the reason in err. */
+lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen);
+/* replaces: PyCUDA garbage-collected DeviceAllocation / context teardown at exit */
+void lbm_destroy(lbm_ctx* c);
+const char* lbm_last_error(const lbm_ctx* c);
+
+/* --- state in ---------------------------------------------------------------------- */
+/* replaces: fin = equ(rho=1, InitVel) on the host + memcpy_htod (MRT_GPU.py:262-267,323-328);
+ * computed on the device. */
+int lbm_init_equilibrium(lbm_ctx* c);
+/* replaces: per-plane transpose + cuda.memcpy_htod(fin_g, fin) (MRT_GPU.py:283-289,323).
+ * fin_host is the WHOLE-lattice array fin[9][nx][ny]; the context reads its own rows
+ * y0 .. y0+ny_local-1.  host_dtype is LBM_F32 or LBM_F64 (converted if it differs). */
+int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype);
+
+/* --- time loop --------------------------------------------------------------------- */
+/* replaces: funRT(...); funBC(...) launched from the Python loop (MRT_GPU.py:707-732).
+ * Enqueues nsteps fused steps and returns without waiting (errors surface at the next
+ * synchronising call, like pycuda LaunchError).  With an RCCL communicator attached the
+ * one-row halo exchange with the slab neighbours is part of every step. */
+int lbm_step(lbm_ctx* c, int nsteps);
+/* replaces: the implicit synchronisation of cuda.memcpy_dtoh (MRT_GPU.py:755) */
+int lbm_sync(lbm_ctx* c);
+/* replaces: the commented cuda.Event timing (MRTTiledPull.py:364-365,536-549): runs nsteps
+ * steps between two HIP events on the compute stream and returns the elapsed milliseconds */
+int lbm_time_steps(lbm_ctx* c, int nsteps, double* ms);
+/* iterations performed since the last lbm_init_equilibrium / lbm_set_state */
+long long lbm_steps_done(const lbm_ctx* c);
+
+/* --- state out --------------------------------------------------------------------- */
+/* replaces: cuda.memcpy_dtoh(fin, ftemp_g); memcpy_dtoh(rho, rho_g); memcpy_dtoh(u, u_g)
+ * + transposes (MRT_GPU.py:755-760).  Synchronises.  u_host[2][nx][ny], rho_host[nx][ny]
+ * receive the macroscopic fields computed in the LAST iteration (one-step lag of the
+ * reference: u_g/rho_g are written inside funRT before collide/stream); fin_host
+ * [9][nx][ny] receives the current populations (post stream + wall rules).  Any pointer
+ * may be NULL.  Whole-lattice arrays; only this context's rows are written. */
+int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int host_dtype);
+
+/* --- slab decomposition, externally driven exchange ---------------------------------- */
+/* No reference counterpart (the reference is single-GPU, MRT_GPU.py:29).  A step of a slab
+ * is split so that a host-language driver can move halos with any transport:
+ *     lbm_halo_export(side) on both neighbours -> transport -> lbm_halo_import(side)
+ *     lbm_step_edges()      rows 0 and ny_local-1 (need the imported halo)
+ *     lbm_step_interior()   rows 1 .. ny_local-2
+ *     lbm_step_finish()     swap lattices, count the step
+ * lbm_halo_elems() = elements of one packed halo (3 planes x nx).  buf may be device or
+ * host memory.  Exports read the rows written by the previous step. */
+int lbm_halo_elems(const lbm_ctx* c);
+int lbm_halo_export(lbm_ctx* c, int side, void* buf);
+int lbm_halo_import(lbm_ctx* c, int side, const void* buf);
+int lbm_step_edges(lbm_ctx* c);
+int lbm_step_interior(lbm_ctx* c);
+int lbm_step_finish(lbm_ctx* c);
+
+/* --- slab decomposition, RCCL exchange inside lbm_step -------------------------------- */
+/* uid_out: 128 bytes (ncclUniqueId) created on one rank and distributed by the caller
+ * (e.g. torch.distributed broadcast).  After lbm_comm_init, lbm_step() exchanges halos with
+ * rank-1 / rank+1 by ncclSend/ncclRecv on a second HIP stream, overlapped with the
+ * interior rows. */
+int lbm_comm_unique_id(void* uid_out128);
+int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128);
+
+/* --- measurement --------------------------------------------------------------------- */
+/* Device-to-device streaming copy of `bytes` bytes (read + write), `iters` times; returns
+ * achieved (read+write) GB/s: the achievable-bandwidth denominator next to the 8 TB/s peak. */
+int lbm_copy_bandwidth(lbm_ctx* c, size_t bytes, int iters, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_H */

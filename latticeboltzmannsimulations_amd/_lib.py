@@ -1,0 +1,94 @@
+"""Loader for liblbm_hip.so (the C ABI of include/lbm.h) -- ctypes only, no torch types.
+
+The product path has NO CPU fallback: if the shared library is missing or cannot be
+loaded, every entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "liblbm_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "lbm.h")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+LINK_FLAGS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+
+LBM_F32, LBM_F64 = 0, 1
+LBM_SRT, LBM_TRT, LBM_MRT = 0, 1, 2
+LBM_SEM_MRT_PY, LBM_SEM_MRT_GPU = 0, 1
+LBM_KERNEL_AUTO, LBM_KERNEL_GENERIC, LBM_KERNEL_VEC = 0, 1, 2
+LBM_SIDE_LOW, LBM_SIDE_HIGH = 0, 1
+
+
+class lbm_params(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("nx", ctypes.c_int32), ("ny", ctypes.c_int32),
+                ("y0", ctypes.c_int32), ("ny_local", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("collision", ctypes.c_int32), ("semantics", ctypes.c_int32), ("kernel", ctypes.c_int32),
+                ("turb", ctypes.c_int32), ("device", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("uLB", ctypes.c_double), ("omega", ctypes.c_double), ("omegam", ctypes.c_double),
+                ("omega_e", ctypes.c_double), ("omega_eps", ctypes.c_double), ("omega_q", ctypes.c_double)]
+
+
+def sources():
+    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".hpp"))] + [HEADER]
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into liblbm_hip.so next to this file (in-tree)."""
+    srcs = sources()
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH] + [s for s in srcs if s.endswith(".hip")] + LINK_FLAGS
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); exactly the entry points declared in include/lbm.h
+_vp, _i, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+SIGNATURES = {
+    "lbm_abi_version": (_i, []),
+    "lbm_device_count": (_i, []),
+    "lbm_create": (_vp, [ctypes.POINTER(lbm_params), ctypes.c_char_p, ctypes.c_size_t]),
+    "lbm_destroy": (None, [_vp]),
+    "lbm_last_error": (ctypes.c_char_p, [_vp]),
+    "lbm_init_equilibrium": (_i, [_vp]),
+    "lbm_set_state": (_i, [_vp, _vp, _i]),
+    "lbm_step": (_i, [_vp, _i]),
+    "lbm_sync": (_i, [_vp]),
+    "lbm_time_steps": (_i, [_vp, _i, ctypes.POINTER(_d)]),
+    "lbm_steps_done": (ctypes.c_longlong, [_vp]),
+    "lbm_get_fields": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "lbm_halo_elems": (_i, [_vp]),
+    "lbm_halo_export": (_i, [_vp, _i, _vp]),
+    "lbm_halo_import": (_i, [_vp, _i, _vp]),
+    "lbm_step_edges": (_i, [_vp]),
+    "lbm_step_interior": (_i, [_vp]),
+    "lbm_step_finish": (_i, [_vp]),
+    "lbm_comm_unique_id": (_i, [_vp]),
+    "lbm_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "lbm_copy_bandwidth": (_i, [_vp, ctypes.c_size_t, _i, ctypes.POINTER(_d)]),
+}
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if an exported symbol is missing
+            f.restype, f.argtypes = res, args
+        if L.lbm_abi_version() != 1:
+            raise RuntimeError("liblbm_hip.so ABI version mismatch")
+        _lib = L
+    return _lib

@@ -1,0 +1,273 @@
+// lbm_device.hpp -- device-side D2Q9 operators shared by every kernel of liblbm_hip.
+//
+// Arithmetic contract: compiled with -ffp-contract=off, every + - * / below is ONE IEEE
+// operation in the order written, so results are bit-identical to a scalar CPU evaluation
+// of the same expressions (the parity tests rely on this).  Operation order follows the
+// reference scripts; each operator cites the lines it restates.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lbm {
+
+constexpr int Q = 9;
+constexpr int GH = 4;  // ghost/pad columns on each side of a row (keeps x = 0 16-byte aligned)
+
+// a1: lattice vectors, MRT.py:138-140 (k: 0 rest, 1 E, 2 N, 3 W, 4 S, 5 NE, 6 NW, 7 SW, 8 SE).
+// A population moves from (x, y) to (x + cx, y - cy): y = 0 is the lid (MRT_GPU.py:412-413).
+__host__ __device__ constexpr int cxk(int k) { return k == 1 || k == 5 || k == 8 ? 1 : (k == 3 || k == 6 || k == 7 ? -1 : 0); }
+__host__ __device__ constexpr int cyk(int k) { return k == 2 || k == 5 || k == 6 ? 1 : (k == 4 || k == 7 || k == 8 ? -1 : 0); }
+
+enum { SEM_PY = 0, SEM_GPU = 1 };
+enum { C_SRT = 0, C_TRT = 1, C_MRT = 2 };
+
+template <typename R>
+struct Relax {  // a2: MRT_GPU.py:63-93
+    R uLB, w_nu, w_m, w_e, w_eps, w_q;
+};
+
+// Destination window of direction k (a7).  SEM_PY: the truncated slices of MRT.py:404-414;
+// SEM_GPU: "neighbour inside the lattice", MRT_GPU.py:412.  gy is the GLOBAL row.
+template <int SEM>
+__device__ __forceinline__ bool in_window(int k, int x, int gy, int X, int Y) {
+    const int cx = cxk(k), cy = cyk(k);
+    bool ok = true;
+    if (SEM == SEM_PY) {
+        if (cx > 0) ok = ok && (x >= 1) && (x <= X - 2);
+        if (cx < 0) ok = ok && (x <= X - 3);
+        if (cy > 0) ok = ok && (gy <= Y - 3);
+        if (cy < 0) ok = ok && (gy >= 1) && (gy <= Y - 2);
+    } else {
+        if (cx > 0) ok = ok && (x >= 1);
+        if (cx < 0) ok = ok && (x <= X - 2);
+        if (cy > 0) ok = ok && (gy <= Y - 2);
+        if (cy < 0) ok = ok && (gy >= 1);
+    }
+    return ok;
+}
+
+// a3: equilibrium, MRT.py:213-231 / MRT_GPU.py:408-410.  cu is formed without the
+// multiplications by 0 and +-1 of the reference (value-identical in IEEE arithmetic).
+template <typename R>
+__device__ __forceinline__ R cu_of(int k, R ux, R uy) {
+    switch (k) {
+        case 1: return ux;
+        case 2: return uy;
+        case 3: return -ux;
+        case 4: return -uy;
+        case 5: return ux + uy;
+        case 6: return -ux + uy;
+        case 7: return -ux + -uy;
+        case 8: return ux + -uy;
+        default: return (R)0;
+    }
+}
+template <typename R>
+__device__ __forceinline__ R weight(int k) {
+    return k == 0 ? (R)(4.0 / 9.0) : (k < 5 ? (R)(1.0 / 9.0) : (R)(1.0 / 36.));
+}
+template <typename R>
+__device__ __forceinline__ void equ(R rho, R ux, R uy, R (&feq)[Q]) {
+    const R usqr = ux * ux + uy * uy;
+    const R c = (R)1.5 * usqr;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const R cu = cu_of<R>(k, ux, uy);
+        feq[k] = (rho * weight<R>(k)) * ((((R)1. + (R)3.0 * cu) + ((R)4.5 * cu) * cu) - c);
+    }
+}
+
+// a4 + a5: moments with the macroscopic wall overrides (MRT.py:292,320-321,337,341-342;
+// MRT_GPU.py:389-405).  rho_sum is the plain sum (used by nothing but kept for clarity).
+template <typename R>
+__device__ __forceinline__ void macros(const R (&f)[Q], int x, int gy, int X, int Y, R uLB, R& rho, R& ux, R& uy) {
+    rho = ((((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7]) + f[8]);
+    ux = (((((f[1] - f[3]) + f[5]) - f[6]) - f[7]) + f[8]) / rho;
+    uy = (((((f[2] - f[4]) + f[5]) + f[6]) - f[7]) - f[8]) / rho;
+    if (x == 0 || x == X - 1 || gy == Y - 1) { ux = (R)0; uy = (R)0; }
+    if (gy == 0) {
+        rho = ((f[0] + f[1]) + f[3]) + (R)2. * ((f[2] + f[5]) + f[6]);
+        ux = uLB; uy = (R)0;
+    }
+}
+
+// a6: collision.  SRT MRT.py:396 / MRT_GPU.py:413; TRT MRT_GPU.py:455-462,514-525;
+// MRT MRT_GPU.py:633-655 (m = M f with jx = m3, jy = m5 from the raw populations, the
+// reference's own m_eq polynomial, f* = Minv m).  Zero matrix entries are skipped and the
+// +-1, +-2, +-4 entries of M are exact scalings: value-identical to the dense products.
+template <typename R, int COLL>
+__device__ __forceinline__ void collide(const R (&f)[Q], R rho, const R (&feq)[Q], const Relax<R>& w, R (&out)[Q]) {
+    if (COLL == C_SRT) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) out[k] = f[k] - w.w_nu * (f[k] - feq[k]);
+    } else if (COLL == C_TRT) {
+        R fp[Q], fm[Q], ep[Q], em[Q];
+        constexpr int pa[4] = {2, 5, 6, 1}, pb[4] = {4, 7, 8, 3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = pa[i], b = pb[i];
+            fp[a] = (R)0.5 * (f[a] + f[b]); fp[b] = fp[a];
+            fm[a] = (R)0.5 * (f[a] - f[b]); fm[b] = -fm[a];
+            ep[a] = (R)0.5 * (feq[a] + feq[b]); ep[b] = ep[a];
+            em[a] = (R)0.5 * (feq[a] - feq[b]); em[b] = -em[a];
+        }
+        fp[0] = f[0]; fm[0] = (R)0; ep[0] = feq[0]; em[0] = (R)0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) out[k] = (f[k] - w.w_nu * (fp[k] - ep[k])) - w.w_m * (fm[k] - em[k]);
+    } else {
+        R m[Q], meq[Q];
+        // rows of M_GS (MRT.py:163-173), left-to-right sums
+        m[0] = (((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7]) + f[8];
+        m[1] = ((((((((R)-4 * f[0] - f[1]) - f[2]) - f[3]) - f[4]) + (R)2 * f[5]) + (R)2 * f[6]) + (R)2 * f[7]) + (R)2 * f[8];
+        m[2] = ((((((((R)4 * f[0] - (R)2 * f[1]) - (R)2 * f[2]) - (R)2 * f[3]) - (R)2 * f[4]) + f[5]) + f[6]) + f[7]) + f[8];
+        m[3] = ((((f[1] - f[3]) + f[5]) - f[6]) - f[7]) + f[8];
+        m[4] = (((((R)-2 * f[1] + (R)2 * f[3]) + f[5]) - f[6]) - f[7]) + f[8];
+        m[5] = ((((f[2] - f[4]) + f[5]) + f[6]) - f[7]) - f[8];
+        m[6] = (((((R)-2 * f[2] + (R)2 * f[4]) + f[5]) + f[6]) - f[7]) - f[8];
+        m[7] = ((f[1] - f[2]) + f[3]) - f[4];
+        m[8] = ((f[5] - f[6]) + f[7]) - f[8];
+        const R jx = m[3], jy = m[5];
+        meq[0] = rho;
+        meq[1] = (R)-2.0 * rho + (R)3.0 * (jx * jx + jy * jy);
+        meq[2] = ((R)-3.0 * (jx * jx + jy * jy) + rho) + (R)9.0 * (((jx * jx) * jy) * jy);
+        meq[3] = m[3];
+        meq[4] = -jx + (R)3.0 * ((jx * jx) * jx);
+        meq[5] = m[5];
+        meq[6] = -jy + (R)3.0 * ((jy * jy) * jy);
+        meq[7] = jx * jx - jy * jy;
+        meq[8] = jx * jy;
+        const R wv[Q] = {(R)0, w.w_e, w.w_eps, (R)0, w.w_q, (R)0, w.w_q, w.w_nu, w.w_nu};
+#pragma unroll
+        for (int k = 0; k < Q; ++k) m[k] = m[k] - wv[k] * (m[k] - meq[k]);
+        // rows of M_GS_INV (MRT.py:175-183)
+        const R a9 = (R)(1.0 / 9), a36 = (R)(1.0 / 36), a18 = (R)(1.0 / 18), a6 = (R)(1.0 / 6),
+                a12 = (R)(1.0 / 12), a4 = (R)(1.0 / 4);
+        out[0] = (a9 * m[0] + -a9 * m[1]) + a9 * m[2];
+        out[1] = ((((a9 * m[0] + -a36 * m[1]) + -a18 * m[2]) + a6 * m[3]) + -a6 * m[4]) + a4 * m[7];
+        out[2] = ((((a9 * m[0] + -a36 * m[1]) + -a18 * m[2]) + a6 * m[5]) + -a6 * m[6]) + -a4 * m[7];
+        out[3] = ((((a9 * m[0] + -a36 * m[1]) + -a18 * m[2]) + -a6 * m[3]) + a6 * m[4]) + a4 * m[7];
+        out[4] = ((((a9 * m[0] + -a36 * m[1]) + -a18 * m[2]) + -a6 * m[5]) + a6 * m[6]) + -a4 * m[7];
+        out[5] = ((((((a9 * m[0] + a18 * m[1]) + a36 * m[2]) + a6 * m[3]) + a12 * m[4]) + a6 * m[5]) + a12 * m[6]) + a4 * m[8];
+        out[6] = ((((((a9 * m[0] + a18 * m[1]) + a36 * m[2]) + -a6 * m[3]) + -a12 * m[4]) + a6 * m[5]) + a12 * m[6]) + -a4 * m[8];
+        out[7] = ((((((a9 * m[0] + a18 * m[1]) + a36 * m[2]) + -a6 * m[3]) + -a12 * m[4]) + -a6 * m[5]) + -a12 * m[6]) + a4 * m[8];
+        out[8] = ((((((a9 * m[0] + a18 * m[1]) + a36 * m[2]) + a6 * m[3]) + a12 * m[4]) + -a6 * m[5]) + -a12 * m[6]) + -a4 * m[8];
+    }
+}
+
+// a8: wall rules on the populations of ONE perimeter cell, given the equilibrium of the
+// previous macroscopic state of that cell.  SEM_PY: MRT.py:450-453 in statement order
+// (left equilibrium, right mirror pairing, bottom, lid); SEM_GPU: MRT_GPU.py:674-692
+// (x rule if / else-if, then y rule if / else-if, opposite pairing).
+template <typename R, int SEM>
+__device__ __forceinline__ void wall_rules(R (&g)[Q], const R (&fe)[Q], int x, int gy, int X, int Y) {
+    if (SEM == SEM_PY) {
+        if (x == 0) { g[1] = fe[1]; g[5] = fe[5]; g[8] = fe[8]; }
+        if (x == X - 1) {
+            const R a = -fe[1] + (fe[3] + g[1]), b = -fe[5] + (fe[6] + g[5]), c = -fe[8] + (fe[7] + g[8]);
+            g[3] = a; g[6] = b; g[7] = c;
+        }
+        if (gy == Y - 1) {
+            const R a = -fe[4] + (fe[2] + g[4]), b = -fe[7] + (fe[5] + g[7]), c = -fe[8] + (fe[6] + g[8]);
+            g[2] = a; g[5] = b; g[6] = c;
+        }
+        if (gy == 0) {
+            const R a = -fe[2] + (fe[4] + g[2]), b = -fe[5] + (fe[7] + g[5]), c = -fe[6] + (fe[8] + g[6]);
+            g[4] = a; g[7] = b; g[8] = c;
+        }
+    } else {
+        if (x == 0) {
+            g[1] = (fe[1] - fe[3]) + g[3];
+            g[5] = (fe[5] - fe[7]) + g[7];
+            g[8] = (fe[8] - fe[6]) + g[6];
+        } else if (x == X - 1) {
+            g[3] = (-fe[1] + fe[3]) + g[1];
+            g[6] = (-fe[8] + fe[6]) + g[8];
+            g[7] = (-fe[5] + fe[7]) + g[5];
+        }
+        if (gy == Y - 1) {
+            g[2] = (-fe[4] + fe[2]) + g[4];
+            g[5] = (-fe[7] + fe[5]) + g[7];
+            g[6] = (-fe[8] + fe[6]) + g[8];
+        } else if (gy == 0) {
+            g[4] = (-fe[2] + fe[4]) + g[2];
+            g[7] = (-fe[5] + fe[7]) + g[5];
+            g[8] = (-fe[6] + fe[8]) + g[6];
+        }
+    }
+}
+
+// Addressing of one padded plane set.  Local row y in [-1, ny], column x in [-GH, nx+GH).
+struct Geo {
+    long long plane;  // elements between consecutive direction planes
+    int pitch;        // elements per row (nx + 2*GH, multiple of 4)
+    int nx, ny;       // columns, local rows
+    int y0, NY;       // first global row of this slab, global height
+    __host__ __device__ __forceinline__ long long at(int x, int y) const { return (long long)(y + 1) * pitch + GH + x; }
+};
+
+// Where a perimeter cell parks the density of its last macroscopic state: slot 0 of the
+// adjacent ghost cell (slot 0 of a ghost cell is never pulled).
+__device__ __forceinline__ long long wall_rho_at(const Geo& g, int x, int y, int gy) {
+    if (gy == 0) return g.at(x, y - 1);
+    if (gy == g.NY - 1) return g.at(x, y + 1);
+    if (x == 0) return g.at(-1, y);
+    return g.at(g.nx, y);
+}
+
+// Gather the post-stream, post-wall-rule populations of cell (x, y) from a lattice that
+// holds post-collision values (+ kept slots + parked wall densities); raw != 0: the lattice
+// holds plain populations (state just set by the host), nothing to stream.
+template <typename R, int SEM>
+__device__ __forceinline__ void gather(const R* __restrict__ src, const Geo& geo, int raw, R uLB, int x, int y, R (&g)[Q]) {
+    const int gy = geo.y0 + y;
+    if (raw) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) g[k] = src[k * geo.plane + geo.at(x, y)];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) g[k] = src[k * geo.plane + geo.at(x - cxk(k), y + cyk(k))];
+    if (x == 0 || x == geo.nx - 1 || gy == 0 || gy == geo.NY - 1) {
+        const R rho_w = src[wall_rho_at(geo, x, y, gy)];
+        R fe[Q];
+        equ<R>(rho_w, gy == 0 ? uLB : (R)0, (R)0, fe);
+        wall_rules<R, SEM>(g, fe, x, gy, geo.nx, geo.NY);
+    }
+}
+
+// One fused update of cell (x, y): gather -> (kept slots) -> moments -> collide -> store.
+template <typename R, int COLL, int SEM>
+__device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
+                                            const Relax<R>& w, int raw, int x, int y) {
+    const int X = geo.nx, Y = geo.NY, gy = geo.y0 + y;
+    R g[Q];
+    gather<R, SEM>(src, geo, raw, w.uLB, x, y, g);
+    // kept slots: a slot outside its streaming window keeps its value; park it where the
+    // next pull of this cell will look for it.
+    const bool near_edge = (x <= 0) || (x >= X - 2) || (gy <= 0) || (gy >= Y - 2);
+    if (near_edge) {
+#pragma unroll
+        for (int k = 1; k < Q; ++k)
+            if (!in_window<SEM>(k, x, gy, X, Y)) dst[k * geo.plane + geo.at(x - cxk(k), y + cyk(k))] = g[k];
+    }
+    R rho, ux, uy, fe[Q], out[Q];
+    macros<R>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
+    equ<R>(rho, ux, uy, fe);
+    collide<R, COLL>(g, rho, fe, w, out);
+    const long long me = geo.at(x, y);
+    if (!near_edge) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) dst[k * geo.plane + me] = out[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            // skip the slot if the receiving cell exists but does not stream it (it is that
+            // cell's kept slot, written by the receiving cell itself)
+            const int dx = x + cxk(k), dgy = gy - cyk(k);
+            const bool inside = dx >= 0 && dx < X && dgy >= 0 && dgy < Y;
+            if (!inside || in_window<SEM>(k, dx, dgy, X, Y)) dst[k * geo.plane + me] = out[k];
+        }
+        if (x == 0 || x == X - 1 || gy == 0 || gy == Y - 1) dst[wall_rho_at(geo, x, y, gy)] = rho;
+    }
+}
+
+}  // namespace lbm

@@ -1,0 +1,622 @@
+// lbm_hip.hip -- liblbm_hip.so: kernels, context and the C ABI declared in include/lbm.h.
+// gfx950 only.  See DESIGN.md for the data layout and the per-kernel roofline notes.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lbm.h"
+#include "lbm_device.hpp"
+
+using namespace lbm;
+
+// ------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------
+constexpr int BLK = 256;
+
+// Generic fused step: one thread per cell, rows y = row0 + blockIdx.y * row_stride.
+template <typename R, int COLL, int SEM>
+__global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src, R* __restrict__ dst, Geo geo,
+                                                      Relax<R> w, int raw, int row0, int row_stride) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = row0 + blockIdx.y * row_stride;
+    if (x >= geo.nx) return;
+    update_cell<R, COLL, SEM>(src, dst, geo, w, raw, x, y);
+}
+
+// init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
+template <typename R>
+__global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    R fe[Q];
+    equ<R>((R)1, (geo.y0 + y) == 0 ? uLB : (R)0, (R)0, fe);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) lat[k * geo.plane + geo.at(x, y)] = fe[k];
+}
+
+// staging (reference host layout, [9][nx][ny_local], y fastest) -> raw lattice
+template <typename R>
+__global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* __restrict__ lat, Geo geo) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    const long long n = (long long)geo.nx * geo.ny;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) lat[k * geo.plane + geo.at(x, y)] = stage[k * n + (long long)x * geo.ny + y];
+}
+
+// lattice -> staging: current populations (post stream + wall rules) in host layout
+template <typename R, int SEM>
+__global__ __launch_bounds__(BLK) void k_export_fin(const R* __restrict__ src, Geo geo, int raw, R uLB,
+                                                    R* __restrict__ stage) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    R g[Q];
+    gather<R, SEM>(src, geo, raw, uLB, x, y, g);
+    const long long n = (long long)geo.nx * geo.ny;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) stage[k * n + (long long)x * geo.ny + y] = g[k];
+}
+
+// lattice -> staging: macroscopic fields (with wall overrides) of the populations gathered
+// from `src`; stage = [ux | uy | rho], each [nx][ny_local]
+template <typename R, int SEM>
+__global__ __launch_bounds__(BLK) void k_export_macro(const R* __restrict__ src, Geo geo, int raw, R uLB,
+                                                      R* __restrict__ stage) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    R g[Q], rho, ux, uy;
+    gather<R, SEM>(src, geo, raw, uLB, x, y, g);
+    macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
+    const long long n = (long long)geo.nx * geo.ny;
+    const long long o = (long long)x * geo.ny + y;
+    stage[o] = ux;
+    stage[n + o] = uy;
+    stage[2 * n + o] = rho;
+}
+
+__global__ __launch_bounds__(BLK) void k_copy16(const uint4* __restrict__ a, uint4* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * BLK;
+    for (; i < n; i += stride) b[i] = a[i];
+}
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+struct lbm_ctx {
+    lbm_params p{};
+    int es = 0;  // element size
+    Geo geo{};
+    void* lat[2] = {nullptr, nullptr};
+    int raw[2] = {1, 1};
+    int cur = 0;  // lat[cur] is the source of the next step
+    long long nsteps = 0;
+    hipStream_t s_compute = nullptr, s_comm = nullptr;
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
+    std::string err;
+};
+
+namespace {
+
+int fail(lbm_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                               \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail((c), LBM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+#define NCCL_TRY(c, expr)                                                                              \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return fail((c), LBM_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));        \
+    } while (0)
+
+template <typename R>
+Relax<R> relax_of(const lbm_params& p) {
+    Relax<R> w;
+    w.uLB = (R)p.uLB; w.w_nu = (R)p.omega; w.w_m = (R)p.omegam;
+    w.w_e = (R)p.omega_e; w.w_eps = (R)p.omega_eps; w.w_q = (R)p.omega_q;
+    return w;
+}
+
+dim3 grid_rows(const lbm_ctx* c, int nrows) { return dim3((c->geo.nx + BLK - 1) / BLK, nrows, 1); }
+
+// launch the fused step on rows row0 + i*stride, i in [0, nrows)
+template <typename R, int COLL, int SEM>
+void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
+    const R* src = (const R*)c->lat[c->cur];
+    R* dst = (R*)c->lat[c->cur ^ 1];
+    hipLaunchKernelGGL((k_step_generic<R, COLL, SEM>), grid_rows(c, nrows), dim3(BLK), 0, s, src, dst, c->geo,
+                       relax_of<R>(c->p), c->raw[c->cur], row0, stride);
+}
+
+template <typename R, int COLL>
+void launch_step_c(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
+    if (c->p.semantics == LBM_SEM_MRT_PY) launch_step_t<R, COLL, SEM_PY>(c, row0, stride, nrows, s);
+    else launch_step_t<R, COLL, SEM_GPU>(c, row0, stride, nrows, s);
+}
+
+template <typename R>
+void launch_step_r(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
+    switch (c->p.collision) {
+        case LBM_SRT: launch_step_c<R, C_SRT>(c, row0, stride, nrows, s); break;
+        case LBM_TRT: launch_step_c<R, C_TRT>(c, row0, stride, nrows, s); break;
+        default: launch_step_c<R, C_MRT>(c, row0, stride, nrows, s); break;
+    }
+}
+
+int launch_step(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
+    if (nrows <= 0) return LBM_OK;
+    if (c->p.dtype == LBM_F32) launch_step_r<float>(c, row0, stride, nrows, s);
+    else launch_step_r<double>(c, row0, stride, nrows, s);
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+void finish_step(lbm_ctx* c) {
+    c->cur ^= 1;
+    c->raw[c->cur] = 0;
+    c->nsteps += 1;
+}
+
+// x-range [lo, hi] of plane k that a slab neighbour actually pulls from a halo row
+void halo_range(const lbm_ctx* c, int k, int* lo, int* hi) {
+    const int X = c->p.nx, cx = cxk(k);
+    int d0, d1;  // destination window in x
+    if (c->p.semantics == LBM_SEM_MRT_PY) {
+        d0 = cx > 0 ? 1 : 0;
+        d1 = cx > 0 ? X - 2 : (cx < 0 ? X - 3 : X - 1);
+    } else {
+        d0 = cx > 0 ? 1 : 0;
+        d1 = cx < 0 ? X - 2 : X - 1;
+    }
+    *lo = d0 - cx;
+    *hi = d1 - cx;
+}
+
+// planes leaving through a side: LOW (towards smaller y): cy = +1 -> k = 2, 5, 6;
+// HIGH (towards larger y): cy = -1 -> k = 4, 7, 8
+const int* side_planes(int side) {
+    static const int low[3] = {2, 5, 6}, high[3] = {4, 7, 8};
+    return side == LBM_SIDE_LOW ? low : high;
+}
+
+char* plane_row(lbm_ctx* c, int which, int k, int y) {
+    return (char*)c->lat[which] + ((size_t)k * c->geo.plane + (size_t)c->geo.at(0, y)) * c->es;
+}
+
+int ensure_stage(lbm_ctx* c, size_t bytes) {
+    if (c->stage_bytes >= bytes) return LBM_OK;
+    if (c->stage) { (void)hipFree(c->stage); c->stage = nullptr; c->stage_bytes = 0; }
+    hipError_t e = hipMalloc(&c->stage, bytes);
+    if (e != hipSuccess) return fail(c, LBM_ERR_NOMEM, std::string("hipMalloc(staging): ") + hipGetErrorString(e));
+    c->stage_bytes = bytes;
+    return LBM_OK;
+}
+
+int sync_all(lbm_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    HIP_TRY(c, hipStreamSynchronize(c->s_comm));
+    return LBM_OK;
+}
+
+// RCCL exchange of the rows of lat[which] with both neighbours, on s_comm
+int enqueue_exchange(lbm_ctx* c, int which) {
+    const ncclDataType_t dt = c->p.dtype == LBM_F32 ? ncclFloat : ncclDouble;
+    const int ny = c->geo.ny;
+    NCCL_TRY(c, ncclGroupStart());
+    for (int side = 0; side < 2; ++side) {
+        const int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
+        if (peer < 0 || peer >= c->nranks) continue;
+        const int* out = side_planes(side);       // leaves through this side
+        const int* in = side_planes(side ^ 1);    // arrives through this side
+        const int send_row = side == LBM_SIDE_LOW ? 0 : ny - 1;
+        const int recv_row = side == LBM_SIDE_LOW ? -1 : ny;
+        for (int j = 0; j < 3; ++j) {
+            int lo, hi;
+            halo_range(c, out[j], &lo, &hi);
+            NCCL_TRY(c, ncclSend(plane_row(c, which, out[j], send_row) + (size_t)lo * c->es, (size_t)(hi - lo + 1), dt,
+                                 peer, c->comm, c->s_comm));
+            halo_range(c, in[j], &lo, &hi);
+            NCCL_TRY(c, ncclRecv(plane_row(c, which, in[j], recv_row) + (size_t)lo * c->es, (size_t)(hi - lo + 1), dt,
+                                 peer, c->comm, c->s_comm));
+        }
+    }
+    NCCL_TRY(c, ncclGroupEnd());
+    return LBM_OK;
+}
+
+int step_many(lbm_ctx* c, int nsteps) {
+    const int ny = c->geo.ny;
+    for (int i = 0; i < nsteps; ++i) {
+        if (c->nranks > 1) {
+            // edges first (they need the halo that was exchanged while the previous
+            // interior ran), then the interior; the next exchange starts as soon as the
+            // edge rows are written and overlaps the interior kernel.
+            if (!c->raw[c->cur]) {
+                if (!c->halo_pending) {  // e.g. right after lbm_comm_init on a stepped lattice
+                    HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_compute));
+                    HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_edges, 0));
+                    int rc = enqueue_exchange(c, c->cur);
+                    if (rc) return rc;
+                    HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
+                }
+                HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_halo, 0));
+            }
+            int rc = launch_step(c, 0, ny - 1, 2, c->s_compute);
+            if (rc) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_compute));
+            rc = launch_step(c, 1, 1, ny - 2, c->s_compute);
+            if (rc) return rc;
+            finish_step(c);
+            HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_edges, 0));
+            rc = enqueue_exchange(c, c->cur);
+            if (rc) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
+            c->halo_pending = true;
+        } else {
+            int rc = launch_step(c, 0, 1, ny, c->s_compute);
+            if (rc) return rc;
+            finish_step(c);
+        }
+    }
+    return LBM_OK;
+}
+
+// host <-> staging helpers.  Host arrays are whole-lattice [planes][nx][NY]; staging is
+// [planes][nx][ny_local].
+template <typename D, typename S>
+void convert_rows(D* dst, const S* src, size_t planes_nx, int ny, int NY, int y0, bool to_host) {
+    for (size_t r = 0; r < planes_nx; ++r)
+        for (int y = 0; y < ny; ++y) {
+            if (to_host) dst[r * NY + y0 + y] = (D)src[r * ny + y];
+            else dst[r * ny + y] = (D)src[r * NY + y0 + y];
+        }
+}
+
+int host_to_stage(lbm_ctx* c, const void* host, int host_dtype, int planes) {
+    const int nx = c->geo.nx, ny = c->geo.ny, NY = c->geo.NY, y0 = c->geo.y0;
+    const size_t rows = (size_t)planes * nx;
+    if (host_dtype == c->p.dtype) {
+        HIP_TRY(c, hipMemcpy2D(c->stage, (size_t)ny * c->es, (const char*)host + (size_t)y0 * c->es, (size_t)NY * c->es,
+                               (size_t)ny * c->es, rows, hipMemcpyHostToDevice));
+        return LBM_OK;
+    }
+    std::vector<char> tmp(rows * ny * c->es);
+    if (c->p.dtype == LBM_F32) convert_rows((float*)tmp.data(), (const double*)host, rows, ny, NY, y0, false);
+    else convert_rows((double*)tmp.data(), (const float*)host, rows, ny, NY, y0, false);
+    HIP_TRY(c, hipMemcpy(c->stage, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    return LBM_OK;
+}
+
+int stage_to_host(lbm_ctx* c, const void* stage, void* host, int host_dtype, int planes) {
+    const int nx = c->geo.nx, ny = c->geo.ny, NY = c->geo.NY, y0 = c->geo.y0;
+    const size_t rows = (size_t)planes * nx;
+    if (host_dtype == c->p.dtype) {
+        HIP_TRY(c, hipMemcpy2D((char*)host + (size_t)y0 * c->es, (size_t)NY * c->es, stage, (size_t)ny * c->es,
+                               (size_t)ny * c->es, rows, hipMemcpyDeviceToHost));
+        return LBM_OK;
+    }
+    std::vector<char> tmp(rows * ny * c->es);
+    HIP_TRY(c, hipMemcpy(tmp.data(), stage, tmp.size(), hipMemcpyDeviceToHost));
+    if (c->p.dtype == LBM_F32) convert_rows((double*)host, (const float*)tmp.data(), rows, ny, NY, y0, true);
+    else convert_rows((float*)host, (const double*)tmp.data(), rows, ny, NY, y0, true);
+    return LBM_OK;
+}
+
+template <typename R>
+int export_fin_t(lbm_ctx* c) {
+    const dim3 g = grid_rows(c, c->geo.ny);
+    const R* src = (const R*)c->lat[c->cur];
+    if (c->p.semantics == LBM_SEM_MRT_PY)
+        hipLaunchKernelGGL((k_export_fin<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[c->cur], (R)c->p.uLB, (R*)c->stage);
+    else
+        hipLaunchKernelGGL((k_export_fin<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[c->cur], (R)c->p.uLB, (R*)c->stage);
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+template <typename R>
+int export_macro_t(lbm_ctx* c) {
+    const dim3 g = grid_rows(c, c->geo.ny);
+    // the fields of the LAST iteration are the moments of the state that iteration started
+    // from, i.e. of the previous lattice (still intact: a step only reads it)
+    const int which = c->nsteps > 0 ? (c->cur ^ 1) : c->cur;
+    const R* src = (const R*)c->lat[which];
+    if (c->p.semantics == LBM_SEM_MRT_PY)
+        hipLaunchKernelGGL((k_export_macro<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage);
+    else
+        hipLaunchKernelGGL((k_export_macro<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage);
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+int lbm_abi_version(void) { return LBM_ABI_VERSION; }
+
+int lbm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
+    auto bail = [&](const std::string& m) -> lbm_ctx* {
+        if (err && errlen) { std::snprintf(err, errlen, "%s", m.c_str()); }
+        return nullptr;
+    };
+    if (!p || p->struct_size != (int32_t)sizeof(lbm_params)) return bail("lbm_params.struct_size mismatch");
+    if (p->nx < 4 || p->ny < 4) return bail("nx, ny must be >= 4");
+    if (p->y0 < 0 || p->ny_local < 2 || p->y0 + p->ny_local > p->ny) return bail("slab rows out of range (ny_local >= 2)");
+    if (p->ny_local > 65535) return bail("ny_local > 65535 not supported");
+    if (p->dtype != LBM_F32 && p->dtype != LBM_F64) return bail("dtype must be LBM_F32 or LBM_F64");
+    if (p->collision < LBM_SRT || p->collision > LBM_MRT) return bail("collision must be SRT, TRT or MRT");
+    if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return bail("bad semantics");
+    if (p->turb != 0) return bail("turb = 1 (Smagorinsky) is not implemented");
+    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_VEC) return bail("bad kernel variant");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return bail(std::string("no HIP device: ") + hipGetErrorString(e));
+    if (p->device < 0 || p->device >= ndev) return bail("device ordinal out of range");
+    if ((e = hipSetDevice(p->device)) != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+    lbm_ctx* c = new (std::nothrow) lbm_ctx();
+    if (!c) return bail("out of host memory");
+    c->p = *p;
+    c->es = p->dtype == LBM_F32 ? 4 : 8;
+    c->geo.nx = p->nx;
+    c->geo.ny = p->ny_local;
+    c->geo.y0 = p->y0;
+    c->geo.NY = p->ny;
+    c->geo.pitch = ((p->nx + 2 * GH) + 3) / 4 * 4;
+    c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2);
+    const size_t bytes = (size_t)Q * c->geo.plane * c->es;
+    auto cleanup = [&](const std::string& m) -> lbm_ctx* { lbm_destroy(c); return bail(m); };
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
+        if ((e = hipMemset(c->lat[i], 0, bytes)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    if ((e = hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&c->s_comm, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
+    if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
+    if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
+    if (lbm_init_equilibrium(c) != LBM_OK) return cleanup(c->err);
+    return c;
+}
+
+void lbm_destroy(lbm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    if (c->s_compute) (void)hipStreamSynchronize(c->s_compute);
+    if (c->s_comm) (void)hipStreamSynchronize(c->s_comm);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    for (int i = 0; i < 2; ++i)
+        if (c->lat[i]) (void)hipFree(c->lat[i]);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);
+    if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
+    if (c->s_comm) (void)hipStreamDestroy(c->s_comm);
+    delete c;
+}
+
+const char* lbm_last_error(const lbm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int lbm_init_equilibrium(lbm_ctx* c) {
+    if (!c) return LBM_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
+    const dim3 g = grid_rows(c, c->geo.ny);
+    if (c->p.dtype == LBM_F32)
+        hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB);
+    else
+        hipLaunchKernelGGL((k_init<double>), g, dim3(BLK), 0, c->s_compute, (double*)c->lat[0], c->geo, (double)c->p.uLB);
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
+    if (!c || !fin_host || (host_dtype != LBM_F32 && host_dtype != LBM_F64)) return fail(c, LBM_ERR_INVALID, "lbm_set_state: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    rc = ensure_stage(c, (size_t)12 * c->geo.nx * c->geo.ny * c->es);
+    if (rc) return rc;
+    rc = host_to_stage(c, fin_host, host_dtype, Q);
+    if (rc) return rc;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
+    const dim3 g = grid_rows(c, c->geo.ny);
+    if (c->p.dtype == LBM_F32)
+        hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo);
+    else
+        hipLaunchKernelGGL((k_import<double>), g, dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return LBM_OK;
+}
+
+int lbm_step(lbm_ctx* c, int nsteps) {
+    if (!c || nsteps < 0) return fail(c, LBM_ERR_INVALID, "lbm_step: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    return step_many(c, nsteps);
+}
+
+int lbm_sync(lbm_ctx* c) {
+    if (!c) return LBM_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    return sync_all(c);
+}
+
+int lbm_time_steps(lbm_ctx* c, int nsteps, double* ms) {
+    if (!c || nsteps < 0 || !ms) return fail(c, LBM_ERR_INVALID, "lbm_time_steps: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    HIP_TRY(c, hipEventRecord(c->ev_t0, c->s_compute));
+    int rc = step_many(c, nsteps);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_t1, c->s_compute));
+    HIP_TRY(c, hipEventSynchronize(c->ev_t1));
+    float f = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&f, c->ev_t0, c->ev_t1));
+    *ms = (double)f;
+    return LBM_OK;
+}
+
+long long lbm_steps_done(const lbm_ctx* c) { return c ? c->nsteps : -1; }
+
+int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int host_dtype) {
+    if (!c || (host_dtype != LBM_F32 && host_dtype != LBM_F64)) return fail(c, LBM_ERR_INVALID, "lbm_get_fields: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->geo.nx * c->geo.ny;
+    rc = ensure_stage(c, (size_t)12 * n * c->es);
+    if (rc) return rc;
+    if (u_host || rho_host) {
+        rc = c->p.dtype == LBM_F32 ? export_macro_t<float>(c) : export_macro_t<double>(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+        if (u_host) { rc = stage_to_host(c, c->stage, u_host, host_dtype, 2); if (rc) return rc; }
+        if (rho_host) { rc = stage_to_host(c, (char*)c->stage + 2 * n * c->es, rho_host, host_dtype, 1); if (rc) return rc; }
+    }
+    if (fin_host) {
+        rc = c->p.dtype == LBM_F32 ? export_fin_t<float>(c) : export_fin_t<double>(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+        rc = stage_to_host(c, c->stage, fin_host, host_dtype, Q);
+        if (rc) return rc;
+    }
+    return LBM_OK;
+}
+
+int lbm_halo_elems(const lbm_ctx* c) { return c ? 3 * c->geo.nx : 0; }
+
+int lbm_halo_export(lbm_ctx* c, int side, void* buf) {
+    if (!c || !buf || (side != LBM_SIDE_LOW && side != LBM_SIDE_HIGH)) return fail(c, LBM_ERR_INVALID, "lbm_halo_export: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    const int* pl = side_planes(side);
+    const int row = side == LBM_SIDE_LOW ? 0 : c->geo.ny - 1;
+    const size_t rb = (size_t)c->geo.nx * c->es;
+    for (int j = 0; j < 3; ++j)
+        HIP_TRY(c, hipMemcpyAsync((char*)buf + j * rb, plane_row(c, c->cur, pl[j], row), rb, hipMemcpyDefault, c->s_compute));
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return LBM_OK;
+}
+
+int lbm_halo_import(lbm_ctx* c, int side, const void* buf) {
+    if (!c || !buf || (side != LBM_SIDE_LOW && side != LBM_SIDE_HIGH)) return fail(c, LBM_ERR_INVALID, "lbm_halo_import: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    const int* pl = side_planes(side ^ 1);  // what arrives through `side` left the neighbour's opposite side
+    const int row = side == LBM_SIDE_LOW ? -1 : c->geo.ny;
+    const size_t rb = (size_t)c->geo.nx * c->es;
+    for (int j = 0; j < 3; ++j) {
+        int lo, hi;
+        halo_range(c, pl[j], &lo, &hi);
+        HIP_TRY(c, hipMemcpyAsync(plane_row(c, c->cur, pl[j], row) + (size_t)lo * c->es, (const char*)buf + j * rb + (size_t)lo * c->es,
+                                  (size_t)(hi - lo + 1) * c->es, hipMemcpyDefault, c->s_compute));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return LBM_OK;
+}
+
+int lbm_step_edges(lbm_ctx* c) {
+    if (!c) return LBM_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    return launch_step(c, 0, c->geo.ny - 1, 2, c->s_compute);
+}
+
+int lbm_step_interior(lbm_ctx* c) {
+    if (!c) return LBM_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    return launch_step(c, 1, 1, c->geo.ny - 2, c->s_compute);
+}
+
+int lbm_step_finish(lbm_ctx* c) {
+    if (!c) return LBM_ERR_INVALID;
+    finish_step(c);
+    return LBM_OK;
+}
+
+int lbm_comm_unique_id(void* uid_out128) {
+    if (!uid_out128) return LBM_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return LBM_ERR_COMM;
+    std::memcpy(uid_out128, &id, sizeof(id));
+    return LBM_OK;
+}
+
+int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
+    if (!c || !uid128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, LBM_ERR_INVALID, "lbm_comm_init: bad argument");
+    if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    ncclUniqueId id;
+    std::memcpy(&id, uid128, sizeof(id));
+    NCCL_TRY(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->nranks = nranks;
+    c->rank = rank;
+    c->halo_pending = false;
+    return LBM_OK;
+}
+
+int lbm_copy_bandwidth(lbm_ctx* c, size_t bytes, int iters, double* gbps) {
+    if (!c || !gbps || iters < 1 || bytes < 16) return fail(c, LBM_ERR_INVALID, "lbm_copy_bandwidth: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    bytes &= ~(size_t)15;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) {
+        if (a) (void)hipFree(a);
+        return fail(c, LBM_ERR_NOMEM, "lbm_copy_bandwidth: hipMalloc failed");
+    }
+    (void)hipMemsetAsync(a, 1, bytes, c->s_compute);
+    const size_t n = bytes / 16;
+    const int blocks = 256 * 8;
+    hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(BLK), 0, c->s_compute, (const uint4*)a, (uint4*)b, n);
+    (void)hipEventRecord(c->ev_t0, c->s_compute);
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(BLK), 0, c->s_compute, (const uint4*)a, (uint4*)b, n);
+    (void)hipEventRecord(c->ev_t1, c->s_compute);
+    hipError_t e = hipEventSynchronize(c->ev_t1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, std::string("lbm_copy_bandwidth: ") + hipGetErrorString(e));
+    *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return LBM_OK;
+}
+
+}  // extern "C"

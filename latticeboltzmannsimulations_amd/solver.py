@@ -1,0 +1,175 @@
+"""Host side of the hot path: a thin ctypes wrapper over liblbm_hip.so that mirrors how the
+reference script drives PyCUDA (MRT_GPU.py:23-30,309-328,701-760): create device state,
+upload / initialise populations, advance N steps, read u / rho / fin back in the reference's
+host layout ([k, x, y], y fastest, y = 0 the lid)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+_DT = {np.dtype(np.float32): L.LBM_F32, np.dtype(np.float64): L.LBM_F64}
+_COLL = {"SRT": L.LBM_SRT, "TRT": L.LBM_TRT, "MRT": L.LBM_MRT}
+_SEM = {"mrt_py": L.LBM_SEM_MRT_PY, "mrt_gpu": L.LBM_SEM_MRT_GPU}
+_KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC}
+
+
+def relaxation(Re, ysize, uLB=0.08, omega_eps=1.2, omega_q=1.2):
+    """Relaxation parameters exactly as the reference script derives them on the host
+    (MRT_GPU.py:63-93): nuLB from the WHOLE lattice height, omega, TRT omegam with
+    Lambda = 1/3.5, MRT vector (omega_e = 1, omega_eps = omega_q = 1.2)."""
+    nuLB = uLB * ysize / Re
+    omega = 2.0 / (6. * nuLB + 1)
+    delTRT = 1.0 / 3.5
+    omegam = 1.0 / (0.5 + (delTRT / ((1 / omega) - 0.5)))
+    return dict(omega=omega, omegam=omegam, omega_e=1.0, omega_eps=omega_eps, omega_q=omega_q)
+
+
+class CavitySolver:
+    """One lattice (or one y-slab of it) resident on one MI355X.
+
+    xsize, ysize : whole lattice (MRT_GPU.py:53-54)
+    Re, uLB      : MRT_GPU.py:47,57
+    RT           : 'SRT' | 'TRT' | 'MRT' (MRT_GPU.py:48)
+    semantics    : 'mrt_gpu' (full streaming windows + NEBB on four walls, MRT_GPU.py:412,674-692)
+                   or 'mrt_py' (the CPU script's windows and wall rules, MRT.py:404-453)
+    dtype        : float32 (what MRT_GPU.py stores, MRT_GPU.py:207) or float64 (what MRT.py computes in)
+    rows         : (y0, ny_local) when this object holds only a slab
+    """
+
+    def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,
+                 device=0, rows=None, kernel="auto", omega_eps=None, omega_q=None):
+        self._h = None
+        self.lib = L.lib()
+        self.nx, self.ny = int(xsize), int(ysize)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in _DT:
+            raise ValueError("dtype must be float32 or float64")
+        if RT not in _COLL:
+            raise ValueError("RT must be 'SRT', 'TRT' or 'MRT'")
+        if semantics not in _SEM:
+            raise ValueError("semantics must be 'mrt_gpu' or 'mrt_py'")
+        if omega_eps is None:
+            omega_eps = 1.0 if semantics == "mrt_py" else 1.2      # MRT.py:72 vs MRT_GPU.py:90
+        if omega_q is None:
+            omega_q = 1.2
+        self.Re, self.RT, self.uLB, self.semantics = float(Re), RT, float(uLB), semantics
+        self.relax = relaxation(self.Re, self.ny, self.uLB, omega_eps, omega_q)
+        self.y0, self.ny_local = (0, self.ny) if rows is None else (int(rows[0]), int(rows[1]))
+        p = L.lbm_params()
+        p.struct_size = ctypes.sizeof(L.lbm_params)
+        p.nx, p.ny, p.y0, p.ny_local = self.nx, self.ny, self.y0, self.ny_local
+        p.dtype, p.collision, p.semantics = _DT[self.dtype], _COLL[RT], _SEM[semantics]
+        p.kernel, p.turb, p.device = _KERNEL[kernel], int(turb), int(device)
+        p.uLB = self.uLB
+        p.omega, p.omegam = self.relax["omega"], self.relax["omegam"]
+        p.omega_e, p.omega_eps, p.omega_q = self.relax["omega_e"], self.relax["omega_eps"], self.relax["omega_q"]
+        err = ctypes.create_string_buffer(512)
+        h = self.lib.lbm_create(ctypes.byref(p), err, len(err))
+        if not h:
+            raise RuntimeError("lbm_create: " + err.value.decode())
+        self._h = ctypes.c_void_p(h)
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.lbm_last_error(self._h).decode()}")
+
+    def close(self):
+        if self._h is not None:
+            self.lib.lbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _host(self, a, shape, name):
+        a = np.asarray(a)
+        if a.dtype not in _DT or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"{name} must be a C-contiguous float32/float64 array of shape {shape}")
+        return a
+
+    # -- state in -----------------------------------------------------------------------
+    def init_equilibrium(self):
+        self._check(self.lib.lbm_init_equilibrium(self._h), "lbm_init_equilibrium")
+
+    def set_state(self, fin):
+        fin = self._host(fin, (9, self.nx, self.ny), "fin")
+        self._check(self.lib.lbm_set_state(self._h, fin.ctypes.data, _DT[fin.dtype]), "lbm_set_state")
+
+    # -- time loop ----------------------------------------------------------------------
+    def step(self, nsteps=1):
+        self._check(self.lib.lbm_step(self._h, int(nsteps)), "lbm_step")
+        return self
+
+    def sync(self):
+        self._check(self.lib.lbm_sync(self._h), "lbm_sync")
+
+    def time_steps(self, nsteps):
+        ms = ctypes.c_double(0.0)
+        self._check(self.lib.lbm_time_steps(self._h, int(nsteps), ctypes.byref(ms)), "lbm_time_steps")
+        return ms.value
+
+    @property
+    def steps_done(self):
+        return int(self.lib.lbm_steps_done(self._h))
+
+    # -- state out ----------------------------------------------------------------------
+    def get_fields(self, want_fin=False, out_dtype=None, u=None, rho=None, fin=None):
+        """Returns (u[2,X,Y], rho[X,Y]) (and fin[9,X,Y]).  Arrays are whole-lattice shaped;
+        a slab writes only its rows y0:y0+ny_local."""
+        dt = self.dtype if out_dtype is None else np.dtype(out_dtype)
+        u = np.zeros((2, self.nx, self.ny), dtype=dt) if u is None else self._host(u, (2, self.nx, self.ny), "u")
+        rho = np.zeros((self.nx, self.ny), dtype=dt) if rho is None else self._host(rho, (self.nx, self.ny), "rho")
+        if want_fin and fin is None:
+            fin = np.zeros((9, self.nx, self.ny), dtype=dt)
+        if fin is not None:
+            fin = self._host(fin, (9, self.nx, self.ny), "fin")
+        self._check(self.lib.lbm_get_fields(self._h, u.ctypes.data, rho.ctypes.data,
+                                            fin.ctypes.data if fin is not None else None, _DT[u.dtype]),
+                    "lbm_get_fields")
+        return (u, rho, fin) if fin is not None else (u, rho)
+
+    # -- slab exchange primitives ---------------------------------------------------------
+    def halo_elems(self):
+        return int(self.lib.lbm_halo_elems(self._h))
+
+    def halo_export(self, side, ptr):
+        self._check(self.lib.lbm_halo_export(self._h, int(side), ctypes.c_void_p(ptr)), "lbm_halo_export")
+
+    def halo_import(self, side, ptr):
+        self._check(self.lib.lbm_halo_import(self._h, int(side), ctypes.c_void_p(ptr)), "lbm_halo_import")
+
+    def step_edges(self):
+        self._check(self.lib.lbm_step_edges(self._h), "lbm_step_edges")
+
+    def step_interior(self):
+        self._check(self.lib.lbm_step_interior(self._h), "lbm_step_interior")
+
+    def step_finish(self):
+        self._check(self.lib.lbm_step_finish(self._h), "lbm_step_finish")
+
+    def comm_init(self, nranks, rank, uid_bytes):
+        buf = ctypes.create_string_buffer(bytes(uid_bytes), 128)
+        self._check(self.lib.lbm_comm_init(self._h, int(nranks), int(rank), buf), "lbm_comm_init")
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=10):
+        g = ctypes.c_double(0.0)
+        self._check(self.lib.lbm_copy_bandwidth(self._h, int(nbytes), int(iters), ctypes.byref(g)), "lbm_copy_bandwidth")
+        return g.value
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    if L.lib().lbm_comm_unique_id(buf) != 0:
+        raise RuntimeError("lbm_comm_unique_id failed")
+    return buf.raw
