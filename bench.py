@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- MLUPS of the D2Q9 MRT lid-driven-cavity step on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one fused pull-stream + collide pass over the whole lattice (all slabs).
+Workload (default): BASELINE.json configs[2] / north_star target -- 4096 x 4096 D2Q9 MRT cavity,
+Re = 1000, fp32, MRT_GPU.py semantics; for N > 1 every rank holds a 4096 x 4096 y-slab of a
+4096 x (4096 N) lattice (weak scaling) and exchanges a one-row halo with its neighbours by
+RCCL send/recv inside lbm_step().  Synthetic input: the reference's own initial state
+(equilibrium at rho = 1 with the moving lid, MRT_GPU.py:262-267), built on the device.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (algorithmic bytes
+per launch / HIP-event kernel time, against 8 TB/s) and `cpu_baseline` (the C oracle timed on
+this host's cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # name: (nx, ny_per_gpu, Re, dtype, RT, semantics, label)
+    "c3": (4096, 4096, 1000.0, "float32", "MRT", "mrt_gpu", "BASELINE configs[2]: 4096x4096 D2Q9 MRT cavity Re=1000 fp32"),
+    "c2": (1024, 1024, 1000.0, "float64", "MRT", "mrt_gpu", "BASELINE configs[1]: 1024x1024 D2Q9 MRT cavity Re=1000 fp64"),
+    "c3f64": (4096, 4096, 1000.0, "float64", "MRT", "mrt_gpu", "4096x4096 D2Q9 MRT cavity Re=1000 fp64"),
+    "c4": (8192, 8192, 3200.0, "float64", "MRT", "mrt_gpu", "BASELINE configs[3] size: 8192x8192 D2Q9 MRT cavity Re=3200 fp64"),
+    "c5": (16384, 2048, 5000.0, "float32", "MRT", "mrt_gpu", "BASELINE configs[4]: 16384 wide, 2048 rows per GPU, Re=5000 fp32"),
+}
+
+
+def host_cores():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU
+    box exposes 256 logical CPUs but grants a 16-CPU share per GPU)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return int(os.environ.get("LBM_BENCH_CPU_THREADS", min(n, 32)))
+
+
+def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=12.0):
+    """The C oracle (oracle/lbm_ref.c, kind 'port') on this host's cores, bounded sample."""
+    from oracle import lbm_ref
+    threads = max(1, min(lbm_ref.max_threads(), host_cores()))
+    lbm_ref.set_threads(threads)
+    o = lbm_ref.CavityOracleC(nx, ny, Re, semantics=semantics, collision=RT, dtype=np.dtype(dtype))
+    o.step(1)                                   # first touch
+    t = time.perf_counter(); o.step(1); one = time.perf_counter() - t
+    n = int(max(2, min(200, budget_s / max(one, 1e-6))))
+    t = time.perf_counter(); o.step(n); dt = time.perf_counter() - t
+    lbm_ref.set_threads(1)
+    return {"value": nx * ny * n / dt / 1e6, "unit": "MLUPS", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the same {nx}x{ny} {dtype} {RT} lattice with the C oracle (oracle/lbm_ref.c, "
+                      f"OpenMP, {threads} threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short side measurements reported under 'other'")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                     "--master-port 29500 bench.py --gpus %d ..." % (a.gpus, a.gpus))
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch                      # plumbing: process group, barrier, device sync
+    import torch.distributed as dist
+    from latticeboltzmannsimulations_amd import CavitySolver
+    from latticeboltzmannsimulations_amd.slab import attach_rccl, partition_rows
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no HIP device visible)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    nx, ny_gpu, Re, dtype, RT, sem, label = CONFIGS[a.config]
+    if a.scaling == "weak":
+        NY = ny_gpu * world
+        rows = (rank * ny_gpu, ny_gpu)
+    else:
+        NY = ny_gpu
+        rows = partition_rows(NY, world)[rank]
+    solver = CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=local_rank,
+                          rows=rows if world > 1 else None, kernel=a.kernel)
+    if world > 1:
+        attach_rccl(solver, rank, world)
+
+    def fence():
+        solver.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    solver.step(a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    ev_ms = solver.time_steps(a.steps)      # HIP events on the compute stream around the K launches
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, ev_ms = float(t[0]), float(t[1])
+
+    cells_total = nx * NY
+    cells_launch = nx * rows[1]
+    es = np.dtype(dtype).itemsize
+    mlups = cells_total * a.steps / dt / 1e6
+    alg_bytes_launch = cells_launch * 2 * 9 * es                 # read 9 + write 9 populations per cell
+    kern_ms = ev_ms / a.steps
+    achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(f"{a.config}:{world}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        other = {}
+        if not a.no_extra and world == 1:
+            try:
+                other["device_copy_GBps"] = round(solver.copy_bandwidth(1 << 30, 10), 1)
+            except Exception as e:      # measurement nicety only
+                other["device_copy_GBps"] = f"failed: {e}"
+        out = {
+            "metric": "MLUPS (million lattice updates/sec) D2Q9 MRT cavity",
+            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": "f32" if dtype == "float32" else "f64", "data": "synthetic",
+            "config": {"workload": label + (f"; {world} y-slabs of {nx}x{rows[1]}, lattice {nx}x{NY}" if world > 1 else ""),
+                       "lattice": [nx, NY], "Re": Re, "collision": RT, "semantics": sem, "kernel": a.kernel,
+                       "halo": "rccl send/recv inside lbm_step, overlapped" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": alg_bytes_launch},
+        }
+        if other:
+            out["other"] = other
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, NY, Re, dtype, RT, sem)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

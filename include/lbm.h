@@ -114,12 +114,14 @@ int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int
 /* --- slab decomposition, externally driven exchange ---------------------------------- */
 /* No reference counterpart (the reference is single-GPU, MRT_GPU.py:29).  A step of a slab
  * is split so that a host-language driver can move halos with any transport:
- *     lbm_halo_export(side) on both neighbours -> transport -> lbm_halo_import(side)
- *     lbm_step_edges()      rows 0 and ny_local-1 (need the imported halo)
+ *     lbm_step_edges()      rows 0 and ny_local-1 (read the ghost rows imported last)
  *     lbm_step_interior()   rows 1 .. ny_local-2
  *     lbm_step_finish()     swap lattices, count the step
+ *     lbm_halo_export(side) on both neighbours -> transport -> lbm_halo_import(side)
+ * i.e. every step is followed by the exchange of the rows it wrote (lbm_get_fields needs
+ * current ghost rows to return the populations of the slab's first and last row).
  * lbm_halo_elems() = elements of one packed halo (3 planes x nx).  buf may be device or
- * host memory.  Exports read the rows written by the previous step. */
+ * host memory. */
 int lbm_halo_elems(const lbm_ctx* c);
 int lbm_halo_export(lbm_ctx* c, int side, void* buf);
 int lbm_halo_import(lbm_ctx* c, int side, const void* buf);

@@ -14,7 +14,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "lbm.h")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
-LINK_FLAGS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+LINK_FLAGS = ["-ldl"]   # RCCL is bound lazily with dlopen inside the library
 
 LBM_F32, LBM_F64 = 0, 1
 LBM_SRT, LBM_TRT, LBM_MRT = 0, 1, 2
@@ -77,6 +77,29 @@ SIGNATURES = {
 }
 
 
+def _preload_torch_runtime():
+    """One process can hold only ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 / librccl (torch/lib); if liblbm_hip.so pulled in /opt/rocm's copies first, a
+    later `import torch` would find no GPU (measured on the MI355X box).  So when torch is
+    installed, load ITS runtime libraries by path first (without importing torch); the
+    DT_NEEDED entries of liblbm_hip.so then resolve to them by SONAME, and torch.distributed
+    (RCCL) and this library share one runtime whichever is imported first."""
+    if os.environ.get("LBM_USE_SYSTEM_ROCM"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libamdhip64.so",):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library; raises (never falls back) when it is missing."""
     global _lib
@@ -84,6 +107,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _preload_torch_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if an exported symbol is missing

@@ -1,7 +1,8 @@
 // lbm_hip.hip -- liblbm_hip.so: kernels, context and the C ABI declared in include/lbm.h.
 // gfx950 only.  See DESIGN.md for the data layout and the per-kernel roofline notes.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // types and prototypes only: RCCL is bound lazily with dlopen (see rccl_api)
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -114,6 +115,48 @@ struct lbm_ctx {
 
 namespace {
 
+// RCCL entry points, resolved on first use.  liblbm_hip.so carries no DT_NEEDED on librccl:
+// single-GPU processes never load it, and in a process that also runs torch.distributed the
+// dlopen below returns the RCCL that is already mapped (same SONAME), so both share one.
+struct rccl_api {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    std::string err;
+};
+
+rccl_api& rccl() {
+    static rccl_api a;
+    if (a.ok || !a.err.empty()) return a;
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) { a.err = std::string("dlopen(librccl): ") + dlerror(); return a; }
+#define RCCL_SYM(field, sym)                                                        \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, #sym));                   \
+    if (!a.field) { a.err = std::string("dlsym(" #sym ") failed"); return a; }
+    RCCL_SYM(GetUniqueId, ncclGetUniqueId)
+    RCCL_SYM(CommInitRank, ncclCommInitRank)
+    RCCL_SYM(CommDestroy, ncclCommDestroy)
+    RCCL_SYM(GroupStart, ncclGroupStart)
+    RCCL_SYM(GroupEnd, ncclGroupEnd)
+    RCCL_SYM(Send, ncclSend)
+    RCCL_SYM(Recv, ncclRecv)
+    RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef RCCL_SYM
+    a.ok = true;
+    return a;
+}
+
 int fail(lbm_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
@@ -130,7 +173,7 @@ int fail(lbm_ctx* c, int code, const std::string& msg) {
     do {                                                                                               \
         ncclResult_t r_ = (expr);                                                                      \
         if (r_ != ncclSuccess)                                                                         \
-            return fail((c), LBM_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));        \
+            return fail((c), LBM_ERR_COMM, std::string(#expr) + ": " + rccl().GetErrorString(r_));     \
     } while (0)
 
 template <typename R>
@@ -226,7 +269,7 @@ int sync_all(lbm_ctx* c) {
 int enqueue_exchange(lbm_ctx* c, int which) {
     const ncclDataType_t dt = c->p.dtype == LBM_F32 ? ncclFloat : ncclDouble;
     const int ny = c->geo.ny;
-    NCCL_TRY(c, ncclGroupStart());
+    NCCL_TRY(c, rccl().GroupStart());
     for (int side = 0; side < 2; ++side) {
         const int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
         if (peer < 0 || peer >= c->nranks) continue;
@@ -237,14 +280,14 @@ int enqueue_exchange(lbm_ctx* c, int which) {
         for (int j = 0; j < 3; ++j) {
             int lo, hi;
             halo_range(c, out[j], &lo, &hi);
-            NCCL_TRY(c, ncclSend(plane_row(c, which, out[j], send_row) + (size_t)lo * c->es, (size_t)(hi - lo + 1), dt,
+            NCCL_TRY(c, rccl().Send(plane_row(c, which, out[j], send_row) + (size_t)lo * c->es, (size_t)(hi - lo + 1), dt,
                                  peer, c->comm, c->s_comm));
             halo_range(c, in[j], &lo, &hi);
-            NCCL_TRY(c, ncclRecv(plane_row(c, which, in[j], recv_row) + (size_t)lo * c->es, (size_t)(hi - lo + 1), dt,
+            NCCL_TRY(c, rccl().Recv(plane_row(c, which, in[j], recv_row) + (size_t)lo * c->es, (size_t)(hi - lo + 1), dt,
                                  peer, c->comm, c->s_comm));
         }
     }
-    NCCL_TRY(c, ncclGroupEnd());
+    NCCL_TRY(c, rccl().GroupEnd());
     return LBM_OK;
 }
 
@@ -400,16 +443,17 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2);
     const size_t bytes = (size_t)Q * c->geo.plane * c->es;
     auto cleanup = [&](const std::string& m) -> lbm_ctx* { lbm_destroy(c); return bail(m); };
-    for (int i = 0; i < 2; ++i) {
-        if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
-        if ((e = hipMemset(c->lat[i], 0, bytes)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
-    }
     if ((e = hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
     if ((e = hipStreamCreateWithFlags(&c->s_comm, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
+        // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
+        if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
+    }
     if (lbm_init_equilibrium(c) != LBM_OK) return cleanup(c->err);
     return c;
 }
@@ -419,7 +463,7 @@ void lbm_destroy(lbm_ctx* c) {
     (void)hipSetDevice(c->p.device);
     if (c->s_compute) (void)hipStreamSynchronize(c->s_compute);
     if (c->s_comm) (void)hipStreamSynchronize(c->s_comm);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     for (int i = 0; i < 2; ++i)
         if (c->lat[i]) (void)hipFree(c->lat[i]);
     if (c->stage) (void)hipFree(c->stage);
@@ -573,8 +617,9 @@ int lbm_step_finish(lbm_ctx* c) {
 int lbm_comm_unique_id(void* uid_out128) {
     if (!uid_out128) return LBM_ERR_INVALID;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    if (!rccl().ok) return LBM_ERR_COMM;
     ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return LBM_ERR_COMM;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return LBM_ERR_COMM;
     std::memcpy(uid_out128, &id, sizeof(id));
     return LBM_OK;
 }
@@ -582,10 +627,11 @@ int lbm_comm_unique_id(void* uid_out128) {
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     if (!c || !uid128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, LBM_ERR_INVALID, "lbm_comm_init: bad argument");
     if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
+    if (!rccl().ok) return fail(c, LBM_ERR_COMM, rccl().err);
     HIP_TRY(c, hipSetDevice(c->p.device));
     ncclUniqueId id;
     std::memcpy(&id, uid128, sizeof(id));
-    NCCL_TRY(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    NCCL_TRY(c, rccl().CommInitRank(&c->comm, nranks, id, rank));
     c->nranks = nranks;
     c->rank = rank;
     c->halo_pending = false;

@@ -1,0 +1,100 @@
+"""CPU tests of the drop-in boundary: liblbm_hip.so loads without a GPU, exports every entry
+point include/lbm.h declares, the ctypes struct matches the C layout, and the product path
+fails loudly (no CPU fallback) when there is no device.  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from latticeboltzmannsimulations_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "lbm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lbm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_bindings_list_the_same_entry_points():
+    names = declared_functions()
+    assert len(names) >= 20
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "liblbm_hip.so not built (run __graft_entry__.build())"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in declared_functions():
+        assert hasattr(L, n), f"{n} declared in include/lbm.h but not exported"
+    assert _lib.lib().lbm_abi_version() == 1
+
+
+def test_library_has_no_static_rccl_dependency():
+    """RCCL is bound lazily (dlopen) so that single-GPU processes never load it and so that
+    torch.distributed and this library share ONE RCCL / HIP runtime in a process."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in out
+    assert "libamdhip64" in out
+
+
+def test_params_struct_layout():
+    assert ctypes.sizeof(_lib.lbm_params) == 12 * 4 + 6 * 8
+    assert _lib.lbm_params.uLB.offset == 48
+
+
+def test_enums_match_header():
+    src = open(os.path.join(ROOT, "include", "lbm.h")).read()
+    for name in ("LBM_F32", "LBM_F64", "LBM_SRT", "LBM_TRT", "LBM_MRT", "LBM_SEM_MRT_PY", "LBM_SEM_MRT_GPU",
+                 "LBM_KERNEL_AUTO", "LBM_KERNEL_GENERIC", "LBM_KERNEL_VEC", "LBM_SIDE_LOW", "LBM_SIDE_HIGH"):
+        m = re.search(name + r"\s*=\s*(-?\d+)", src)
+        assert m and int(m.group(1)) == getattr(_lib, name), name
+
+
+def test_null_arguments_are_rejected_not_dereferenced():
+    L = _lib.lib()
+    assert L.lbm_comm_unique_id(None) == -1            # LBM_ERR_INVALID
+    assert L.lbm_step(None, 1) == -1
+    assert L.lbm_sync(None) == -1
+    assert L.lbm_steps_done(None) == -1
+    assert L.lbm_halo_elems(None) == 0
+    assert L.lbm_last_error(None) == b"null context"
+    L.lbm_destroy(None)
+
+
+def test_create_fails_loudly_without_a_device():
+    L = _lib.lib()
+    if L.lbm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from latticeboltzmannsimulations_amd import CavitySolver
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        CavitySolver(64, 64, 100.0)
+
+
+def test_create_rejects_bad_parameters():
+    L = _lib.lib()
+    err = ctypes.create_string_buffer(256)
+    p = _lib.lbm_params()
+    p.struct_size = 3
+    assert not L.lbm_create(ctypes.byref(p), err, len(err))
+    assert b"struct_size" in err.value
+    p.struct_size = ctypes.sizeof(_lib.lbm_params)
+    p.nx, p.ny, p.y0, p.ny_local = 64, 64, 0, 64
+    p.dtype, p.collision, p.semantics, p.turb = 1, 2, 1, 1
+    assert not L.lbm_create(ctypes.byref(p), err, len(err))
+    assert b"turb" in err.value
+    p.turb, p.ny_local = 0, 1
+    assert not L.lbm_create(ctypes.byref(p), err, len(err))
+    assert b"slab" in err.value
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "latticeboltzmannsimulations_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("oracle/", "").lower() or f == "__never__", (f, "mentions the oracle")

@@ -1,0 +1,249 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C
+ABI (ctypes -> liblbm_hip.so), against the CPU oracle on identical inputs.
+
+Tolerances: the library is compiled with -ffp-contract=off and keeps the reference's operation
+order, so fp64 AND fp32 results are required to be BIT-IDENTICAL to the oracle (np.array_equal);
+north_star's 1e-6 relative tolerance on the centrelines is asserted on top for config C1.
+Nothing here reads /root/reference.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle.lbm_ref import CavityOracleC, set_threads, max_threads      # noqa: E402
+from latticeboltzmannsimulations_amd import CavitySolver, ghia            # noqa: E402
+from latticeboltzmannsimulations_amd.slab import LocalSlabs, partition_rows  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+KERNELS = ["generic", "auto"]
+
+
+def same(solver, oracle, what="state"):
+    u, rho, fin = solver.get_fields(want_fin=True)
+    assert np.array_equal(fin, oracle.fin), f"{what}: fin differs, max abs {np.abs(fin - oracle.fin).max()}"
+    assert np.array_equal(u, oracle.u), f"{what}: u differs"
+    assert np.array_equal(rho, oracle.rho), f"{what}: rho differs"
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("sem", ["mrt_py", "mrt_gpu"])
+@pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hip_step_is_bit_identical_to_oracle(kernel, sem, coll, dtype):
+    for nx, ny in ((16, 16), (40, 24), (300, 20), (24, 300), (1028, 12)):
+        o = CavityOracleC(nx, ny, 100.0, semantics=sem, collision=coll, dtype=dtype)
+        with CavitySolver(nx, ny, 100.0, RT=coll, semantics=sem, dtype=dtype, kernel=kernel) as s:
+            assert np.array_equal(s.get_fields(want_fin=True)[2], o.fin), "initial equilibrium differs"
+            for n in (1, 1, 1, 7, 90):
+                o.step(n); s.step(n)
+                same(s, o, f"{nx}x{ny} after {o.nsteps} steps")
+            assert s.steps_done == 100
+
+
+def test_config_c1_128_re100_1000_steps():
+    """BASELINE.json configs[0]: 128x128, Re = 100, fp64, 1000 steps, MRT.py semantics."""
+    rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
+    o = CavityOracleC(128, 128, 100.0, semantics="mrt_py", collision="SRT").step(1000)
+    with CavitySolver(128, 128, 100.0, RT="SRT", semantics="mrt_py", dtype=np.float64) as s:
+        assert s.relax["omega"] == rec["omega"]
+        s.step(1000)
+        same(s, o, "C1")
+        u, rho = s.get_fields()
+    # north_star gate: centreline u / v within 1e-6 relative (fp64)
+    cx, cy = ghia.centrelines(u, 0.08)
+    ox, oy = ghia.centrelines(o.u, 0.08)
+    assert np.allclose(cx, ox, rtol=1e-6, atol=0) and np.allclose(cy, oy, rtol=1e-6, atol=0)
+    # recorded cross-check (provenance in the JSON)
+    for y, v in zip(rec["ux_mid_column"]["y"], rec["ux_mid_column"]["value_over_uLB"]):
+        assert cx[y] == pytest.approx(v, rel=1e-6, abs=1e-15)
+    for x, v in zip(rec["uy_mid_row"]["x"], rec["uy_mid_row"]["value_over_uLB"]):
+        assert cy[x] == pytest.approx(v, rel=1e-6, abs=1e-15)
+    assert ghia.regression_value(u, 100, 0.08) == pytest.approx(rec["regression_value"], rel=1e-9)
+
+
+@pytest.mark.parametrize("coll,sem", [("MRT", "mrt_gpu"), ("SRT", "mrt_py")])
+def test_config_c2_1024_re1000_100_steps(coll, sem):
+    """BASELINE.json configs[1]: 1024x1024, Re = 1000, fp64, fused pull kernel."""
+    set_threads(min(16, max_threads()))
+    try:
+        o = CavityOracleC(1024, 1024, 1000.0, semantics=sem, collision=coll).step(100)
+    finally:
+        set_threads(1)
+    with CavitySolver(1024, 1024, 1000.0, RT=coll, semantics=sem, dtype=np.float64) as s:
+        s.step(100)
+        same(s, o, "C2")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_batched_steps_equal_single_steps(dtype):
+    a = CavitySolver(96, 80, 400.0, RT="MRT", dtype=dtype)
+    b = CavitySolver(96, 80, 400.0, RT="MRT", dtype=dtype)
+    a.step(37)
+    for _ in range(37):
+        b.step(1)
+    ua, ra, fa = a.get_fields(want_fin=True)
+    ub, rb, fb = b.get_fields(want_fin=True)
+    assert np.array_equal(fa, fb) and np.array_equal(ua, ub) and np.array_equal(ra, rb)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("sem", ["mrt_py", "mrt_gpu"])
+def test_set_state_roundtrip_and_exact_restart(sem):
+    nx, ny = 72, 56
+    with CavitySolver(nx, ny, 100.0, RT="TRT", semantics=sem, dtype=np.float64) as s:
+        s.step(25)
+        _, _, fin25 = s.get_fields(want_fin=True)
+        s.step(30)
+        u55, rho55, fin55 = s.get_fields(want_fin=True)
+    with CavitySolver(nx, ny, 100.0, RT="TRT", semantics=sem, dtype=np.float64) as r:
+        r.set_state(fin25)
+        _, _, back = r.get_fields(want_fin=True)
+        assert np.array_equal(back, fin25)                      # a10 layout contract round trip
+        r.step(30)
+        u, rho, fin = r.get_fields(want_fin=True)
+        assert np.array_equal(fin, fin55) and np.array_equal(u, u55) and np.array_equal(rho, rho55)
+    # host dtype conversion on the boundary
+    with CavitySolver(nx, ny, 100.0, RT="TRT", semantics=sem, dtype=np.float32) as r:
+        r.set_state(fin25)                                      # fp64 host -> fp32 device
+        _, _, back = r.get_fields(want_fin=True, out_dtype=np.float64)
+        assert np.array_equal(back, fin25.astype(np.float32).astype(np.float64))
+
+
+def test_argument_checks():
+    with CavitySolver(32, 32, 100.0) as s:
+        with pytest.raises(ValueError):
+            s.set_state(np.zeros((9, 32, 31)))
+        with pytest.raises(ValueError):
+            s.set_state(np.zeros((9, 32, 32), dtype=np.int32))
+        with pytest.raises(ValueError):
+            s.get_fields(u=np.zeros((2, 32, 32), order="F")[:, ::2])
+    with pytest.raises(ValueError):
+        CavitySolver(32, 32, 100.0, RT="BGK")
+    with pytest.raises(RuntimeError, match="turb"):
+        CavitySolver(32, 32, 100.0, turb=1)
+    with pytest.raises(RuntimeError, match="nx, ny"):
+        CavitySolver(2, 32, 100.0)
+
+
+@pytest.mark.parametrize("sem,coll", [("mrt_gpu", "MRT"), ("mrt_py", "SRT")])
+def test_split_step_equals_fused_step(sem, coll):
+    a = CavitySolver(80, 40, 100.0, RT=coll, semantics=sem, dtype=np.float64)
+    b = CavitySolver(80, 40, 100.0, RT=coll, semantics=sem, dtype=np.float64)
+    a.step(9)
+    for _ in range(9):
+        b.step_edges(); b.step_interior(); b.step_finish()
+    fa, fb = a.get_fields(want_fin=True), b.get_fields(want_fin=True)
+    assert all(np.array_equal(x, y) for x, y in zip(fa, fb))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("sem,coll,dtype", [("mrt_gpu", "MRT", np.float64), ("mrt_gpu", "MRT", np.float32),
+                                            ("mrt_py", "SRT", np.float64), ("mrt_gpu", "TRT", np.float64)])
+@pytest.mark.parametrize("nslabs", [2, 3, 8])
+def test_slabs_on_one_device_equal_single_slab(sem, coll, dtype, nslabs):
+    """T6: S y-slabs (uneven) with halo export/import on ONE device == the undivided lattice."""
+    nx, ny, steps = 132, 67, 40
+    with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=dtype) as one:
+        one.step(steps)
+        u1, r1, f1 = one.get_fields(want_fin=True)
+    slabs = [CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=dtype, rows=r) for r in partition_rows(ny, nslabs)]
+    LocalSlabs(slabs).step(steps)
+    u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
+    for s in slabs:
+        s.get_fields(u=u, rho=rho, fin=fin)
+        s.close()
+    assert np.array_equal(fin, f1) and np.array_equal(u, u1) and np.array_equal(rho, r1)
+
+
+def test_slab_restart_from_global_state():
+    """set_state on slabs reads each slab's rows from the whole-lattice array."""
+    nx, ny = 64, 50
+    with CavitySolver(nx, ny, 100.0, RT="MRT", dtype=np.float64) as one:
+        one.step(20)
+        _, _, f20 = one.get_fields(want_fin=True)
+        one.step(15)
+        u35, r35, f35 = one.get_fields(want_fin=True)
+    slabs = [CavitySolver(nx, ny, 100.0, RT="MRT", dtype=np.float64, rows=r) for r in partition_rows(ny, 3)]
+    for s in slabs:
+        s.set_state(f20)
+    LocalSlabs(slabs).step(15)
+    u = np.zeros_like(u35); rho = np.zeros_like(r35); fin = np.zeros_like(f35)
+    for s in slabs:
+        s.get_fields(u=u, rho=rho, fin=fin)
+        s.close()
+    assert np.array_equal(fin, f35) and np.array_equal(u, u35) and np.array_equal(rho, r35)
+
+
+def test_fp32_tracks_fp64():
+    with CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float64) as d, \
+            CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float32) as f:
+        d.step(500); f.step(500)
+        ud, rd = d.get_fields()
+        uf, rf = f.get_fields(out_dtype=np.float64)
+    assert np.abs(uf - ud).max() / 0.08 < 2e-4
+    assert np.abs(rf - rd).max() < 2e-5
+
+
+def test_full_size_properties_4096_fp32():
+    """BASELINE.json configs[2] size (4096^2, fp32, MRT): properties that need no CPU oracle run --
+    4 slabs == 1 slab bit for bit, generic kernel == default kernel, mass drift bounded, finite."""
+    n, steps = 4096, 6
+    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as one:
+        one.step(steps)
+        u1, r1, f1 = one.get_fields(want_fin=True)
+    assert np.isfinite(f1).all()
+    mass0 = float(n) * n                                   # rho = 1 everywhere at t = 0
+    assert abs(f1.sum(dtype=np.float64) - mass0) / mass0 < 1e-4
+    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, kernel="generic") as g:
+        g.step(steps)
+        ug, rg, fg = g.get_fields(want_fin=True)
+    assert np.array_equal(fg, f1) and np.array_equal(ug, u1) and np.array_equal(rg, r1)
+    del ug, rg, fg
+    slabs = [CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, rows=r) for r in partition_rows(n, 4)]
+    LocalSlabs(slabs).step(steps)
+    u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
+    for s in slabs:
+        s.get_fields(u=u, rho=rho, fin=fin)
+        s.close()
+    assert np.array_equal(fin, f1) and np.array_equal(u, u1) and np.array_equal(rho, r1)
+
+
+def test_rccl_single_rank_communicator_is_transparent():
+    from latticeboltzmannsimulations_amd import comm_unique_id
+    with CavitySolver(64, 64, 100.0, RT="MRT", dtype=np.float64) as a, \
+            CavitySolver(64, 64, 100.0, RT="MRT", dtype=np.float64) as b:
+        b.comm_init(1, 0, comm_unique_id())
+        a.step(12); b.step(12)
+        assert all(np.array_equal(x, y) for x, y in zip(a.get_fields(want_fin=True), b.get_fields(want_fin=True)))
+
+
+def test_timing_and_bandwidth_probes():
+    with CavitySolver(1024, 1024, 1000.0, RT="MRT", dtype=np.float32) as s:
+        s.step(5); s.sync()
+        ms = s.time_steps(20)
+        assert 0 < ms < 1000
+        assert s.copy_bandwidth(1 << 28, 5) > 500.0     # GB/s, any healthy MI355X
+
+
+def test_front_end_drop_in(tmp_path, monkeypatch):
+    """run_cavity with the reference's knobs: outputs at It = 0, P, 2P; VTK files; u / rho shapes."""
+    from latticeboltzmannsimulations_amd.mrt_gpu import run_cavity
+    monkeypatch.chdir(tmp_path)
+    r = run_cavity(maxIt=2001, Re=100.0, RT="MRT", turb=0, xsize=64, ysize=64, Pinterval=1000,
+                   SavePlot=False, SaveVTK=True, quiet=True)
+    assert r.iterations == 2001 and [it for it, _ in r.regression] == [0, 1000, 2000]
+    assert r.u.shape == (2, 64, 64) and r.rho.shape == (64, 64) and r.u.dtype == np.float32
+    for i in range(3):
+        assert os.path.exists(tmp_path / "output" / f"ldc.{i:05d}.vtr")
+    assert r.regression[-1][1] > r.regression[0][1]
+    o = CavityOracleC(64, 64, 100.0, semantics="mrt_gpu", collision="MRT", dtype=np.float32).step(2001)
+    assert np.array_equal(r.u, o.u) and np.array_equal(r.rho, o.rho)
+    with pytest.raises(NotImplementedError):
+        run_cavity(maxIt=1, turb=1, quiet=True)

@@ -1,0 +1,90 @@
+"""CPU tests of the host-side logic around the hot path (rows a2, a10, a11 of SURVEY.md 8):
+relaxation parameters, Ghia table + the reference's metrics, the .vtr writer (byte fixtures
+produced by the reference's own VTKWrapper/pyevtk), slab partitioning."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from latticeboltzmannsimulations_amd import ghia, relaxation
+from latticeboltzmannsimulations_amd.VTKWrapper import saveToVTK
+from latticeboltzmannsimulations_amd.slab import partition_rows, neighbours
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_relaxation_matches_reference_formulas():
+    rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
+    r = relaxation(100.0, 128)
+    assert r["omega"] == rec["omega"]
+    assert r["omega_e"] == 1.0 and r["omega_eps"] == 1.2 and r["omega_q"] == 1.2    # MRT_GPU.py:89-90
+    assert relaxation(5000.0, 16384)["omega"] == rec["omega_by_config"]["C5_16384_Re5000"]
+    assert relaxation(3200.0, 8192)["omega"] == rec["omega_by_config"]["C4_8192_Re3200"]
+
+
+def test_ghia_table_matches_reference_csv_fixture():
+    g = np.load(os.path.join(GOLDEN, "ghia.npz"))
+    assert np.array_equal(ghia.Y_GHIA, g["Y"]) and np.array_equal(ghia.X_GHIA, g["X"])
+    assert np.array_equal(ghia.UX_GHIA, g["Ux"]) and np.array_equal(ghia.UY_GHIA, g["Uy"])
+    assert np.array_equal(ghia.VORTEX_GHIA, g["vortices"])
+    Y, Ux, X, Uy = ghia.ghia_profiles(1000)
+    assert Ux[1] == 0.65928 and Uy[1] == -0.21388
+    with pytest.raises(KeyError):
+        ghia.ghia_profiles(123)
+    xv, yv = ghia.ghia_vortices(100)
+    assert xv.tolist() == [0.6172, 0.0313, 0.9453] and yv.tolist() == [0.7344, 0.0391, 0.0625]
+
+
+def test_sample_rows_match_record():
+    rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
+    assert ghia.sample_rows(128).tolist() == rec["LBMy"]
+
+
+def test_metrics_on_a_synthetic_field():
+    # a field whose middle column reproduces Ghia exactly at the sampled rows -> both metrics ~ 1
+    X = Y = 128
+    u = np.zeros((2, X, Y))
+    _, Ux, _, _ = ghia.ghia_profiles(100)
+    rows = ghia.sample_rows(Y)
+    u[0, X // 2, rows] = Ux[:-1][::-1] * 0.08
+    assert ghia.regression_value(u, 100, 0.08) == pytest.approx(1.0, abs=1e-12)
+    assert ghia.r2_value(u, 100, 0.08) > 0.9999
+    cx, cy = ghia.centrelines(u, 0.08)
+    assert cx.shape == (Y,) and cy.shape == (X,)
+
+
+def test_regression_value_matches_record_on_oracle_field():
+    """MRT.py:559-561 metric on the C1 oracle field equals the value recorded in SURVEY App. C."""
+    from oracle.lbm_numpy import CavityOracle
+    rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
+    o = CavityOracle(128, 128, 100.0, semantics="mrt_py", collision="SRT").step(1000)
+    assert ghia.regression_value(o.u, 100, 0.08) == pytest.approx(rec["regression_value"], rel=1e-12)
+
+
+@pytest.mark.parametrize("fixture", ["vtr_4x3.npz", "vtr_5x4_f32.npz"])
+def test_vtr_bytes_equal_reference_writer(fixture, tmp_path, monkeypatch):
+    g = np.load(os.path.join(GOLDEN, fixture))
+    monkeypatch.chdir(tmp_path)
+    path = saveToVTK((g["ux"], g["uy"], g["uz"]), g["rho"], "ldc", "00007", (g["gx"], g["gy"], g["gz"]))
+    assert path == "./ldc.00007.vtr"
+    assert open(path, "rb").read() == g["vtr"].tobytes()
+
+
+def test_vtr_rejects_mismatched_shapes(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    a = np.zeros((4, 3, 1))
+    with pytest.raises(ValueError):
+        saveToVTK((a, a, a), np.zeros((4, 4, 1)), "p", "0", (np.arange(4.), np.arange(3.), np.arange(1.)))
+
+
+def test_partition_rows():
+    assert partition_rows(4096, 1) == [(0, 4096)]
+    assert partition_rows(8192, 8) == [(i * 1024, 1024) for i in range(8)]
+    p = partition_rows(103, 4)
+    assert [n for _, n in p] == [26, 26, 26, 25] and p[0][0] == 0 and p[-1][0] + p[-1][1] == 103
+    for (a, n), (b, _) in zip(p[:-1], p[1:]):
+        assert a + n == b
+    with pytest.raises(ValueError):
+        partition_rows(7, 4)
+    assert neighbours(0, 4) == (None, 1) and neighbours(3, 4) == (2, None) and neighbours(0, 1) == (None, None)

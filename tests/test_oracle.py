@@ -1,0 +1,176 @@
+"""CPU tests of the oracle (oracle/): the two independent restatements against each other,
+operator identities, the recorded cross-check of SURVEY.md Appendix C, and the physics-level
+pin against the reference's own data file (GhiaData.csv -> tests/golden/ghia.npz).
+
+Parity status of the oracle itself: *parity unpinned at bit level* -- see oracle/README.md.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lbm_numpy as on
+from oracle.lbm_ref import CavityOracleC, set_threads, max_threads
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("sem", ["mrt_py", "mrt_gpu"])
+@pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_numpy_and_c_restatements_agree_bitwise(sem, coll, dtype):
+    for nx, ny in ((16, 16), (24, 16), (12, 40)):
+        a = on.CavityOracle(nx, ny, 100.0, semantics=sem, collision=coll, dtype=dtype)
+        b = CavityOracleC(nx, ny, 100.0, semantics=sem, collision=coll, dtype=dtype)
+        assert np.array_equal(a.fin, b.fin), "initial equilibrium differs"
+        for n in (1, 2, 30):
+            a.step(n); b.step(n)
+            assert np.array_equal(a.fin, b.fin)
+            assert np.array_equal(a.rho, b.rho)
+            assert np.array_equal(a.u, b.u)
+
+
+def test_c_oracle_is_thread_count_invariant():
+    set_threads(1)
+    a = CavityOracleC(48, 40, 400.0, semantics="mrt_gpu", collision="MRT").step(25)
+    set_threads(min(4, max_threads()))
+    b = CavityOracleC(48, 40, 400.0, semantics="mrt_gpu", collision="MRT").step(25)
+    set_threads(1)
+    assert np.array_equal(a.fin, b.fin) and np.array_equal(a.u, b.u)
+
+
+def test_lattice_tables():
+    # MRT.py:138-160
+    assert on.CX.tolist() == [0, 1, 0, -1, 0, 1, -1, -1, 1]
+    assert on.CY.tolist() == [0, 0, 1, 0, -1, 1, 1, -1, -1]
+    assert on.RIGHT == [1, 5, 8] and on.LEFT == [3, 6, 7] and on.TOP == [2, 5, 6] and on.BOT == [4, 7, 8]
+    t = on.weights(np.float64)
+    assert abs(t.sum() - 1.0) < 1e-15 and t[0] == 4.0 / 9.0 and t[1] == 1.0 / 9.0 and t[8] == 1.0 / 36.
+    # M * Minv = I and orthogonal rows
+    assert np.abs(on.M_GS @ on.M_GS_INV - np.eye(9)).max() < 5e-16
+    G = on.M_GS @ on.M_GS.T
+    assert np.abs(G - np.diag(np.diag(G))).max() == 0
+    # rows 3 and 5 of M are the lattice vectors
+    assert on.M_GS[3].tolist() == on.CX.tolist() and on.M_GS[5].tolist() == on.CY.tolist()
+
+
+def test_relaxation_values():
+    rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
+    assert on.relaxation(100.0, 128)["omega"] == rec["omega"]
+    assert on.relaxation(1000.0, 1024)["omega"] == rec["omega_by_config"]["C2_1024_Re1000"]
+    assert on.relaxation(1000.0, 4096)["omega"] == rec["omega_by_config"]["C3_4096_Re1000"]
+    r = on.relaxation(1000.0, 160)
+    # TRT magic parameter Lambda = (1/wp - 1/2)(1/wm - 1/2) = 1/3.5 (MRT_GPU.py:79-80)
+    assert abs((1 / r["omega"] - 0.5) * (1 / r["omegam"] - 0.5) - 1 / 3.5) < 1e-15
+
+
+@pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
+def test_collision_conserves_mass_and_momentum(coll):
+    rng = np.random.default_rng(0)
+    o = on.CavityOracle(8, 8, 100.0, semantics="mrt_gpu", collision=coll)
+    f = o.fin * (1 + 1e-2 * rng.standard_normal(o.fin.shape))
+    # interior-cell relations only: no wall overrides
+    rho = f.sum(axis=0)
+    ux = (f * on.CX.reshape(9, 1, 1)).sum(axis=0) / rho
+    uy = (f * on.CY.reshape(9, 1, 1)).sum(axis=0) / rho
+    feq = on.equ(rho, ux, uy, o.t)
+    out = o.collide(f, rho, feq)
+    assert np.abs(out.sum(axis=0) - rho).max() < 1e-14
+    if coll != "MRT":   # the reference's MRT m_eq uses j, conserved as well; checked separately below
+        assert np.abs((out * on.CX.reshape(9, 1, 1)).sum(axis=0) - rho * ux).max() < 1e-14
+        assert np.abs((out * on.CY.reshape(9, 1, 1)).sum(axis=0) - rho * uy).max() < 1e-14
+    else:
+        assert np.abs((out * on.CX.reshape(9, 1, 1)).sum(axis=0) - (f * on.CX.reshape(9, 1, 1)).sum(axis=0)).max() < 1e-14
+        assert np.abs((out * on.CY.reshape(9, 1, 1)).sum(axis=0) - (f * on.CY.reshape(9, 1, 1)).sum(axis=0)).max() < 1e-14
+
+
+def test_mrt_formula_spot_value():
+    """MRT_GPU.py:636-648 evaluated by hand for one population vector."""
+    o = on.CavityOracle(8, 8, 100.0, semantics="mrt_gpu", collision="MRT")
+    f = np.array([0.44, 0.12, 0.10, 0.11, 0.115, 0.03, 0.027, 0.026, 0.029]).reshape(9, 1, 1)
+    rho = f.sum(axis=0)
+    m = np.einsum("kj,jxy->kxy", on.M_GS, f)
+    jx, jy = m[3], m[5]
+    meq = np.array([rho, -2 * rho + 3 * (jx * jx + jy * jy), -3 * (jx * jx + jy * jy) + rho + 9 * jx * jx * jy * jy,
+                    jx, -jx + 3 * jx ** 3, jy, -jy + 3 * jy ** 3, jx * jx - jy * jy, jx * jy])
+    w = np.array(o.omega_vec).reshape(9, 1, 1)
+    expect = np.einsum("kj,jxy->kxy", on.M_GS_INV, m - w * (m - meq))
+    got = o.collide(f, rho, None)
+    assert np.abs(got - expect).max() < 1e-15
+
+
+def test_windows_tables():
+    """Appendix A.4 (MRT.py:404-414) and the full windows of MRT_GPU.py:412."""
+    X, Y = 10, 12
+    py = on.CavityOracle(X, Y, 100.0, semantics="mrt_py")
+    gp = on.CavityOracle(X, Y, 100.0, semantics="mrt_gpu")
+    exp_py = {0: ((0, X - 1), (0, Y - 1)), 1: ((1, X - 2), (0, Y - 1)), 2: ((0, X - 1), (0, Y - 3)),
+              3: ((0, X - 3), (0, Y - 1)), 4: ((0, X - 1), (1, Y - 2)), 5: ((1, X - 2), (0, Y - 3)),
+              6: ((0, X - 3), (0, Y - 3)), 7: ((0, X - 3), (1, Y - 2)), 8: ((1, X - 2), (1, Y - 2))}
+    for k in range(9):
+        assert py.window(k) == exp_py[k]
+        (x0, x1), (y0, y1) = gp.window(k)
+        cx, cy = int(on.CX[k]), int(on.CY[k])
+        assert (x0, x1) == (max(0, cx), X - 1 + min(0, cx)) and (y0, y1) == (max(0, -cy), Y - 1 + min(0, -cy))
+
+
+def test_mrt_py_frozen_slots():
+    """slots never streamed into and never touched by a wall rule keep their initial
+    value forever, e.g. k = 3, 6, 7 on column X-2 and k = 2 on row Y-2."""
+    N = 20
+    o = on.CavityOracle(N, N, 100.0, semantics="mrt_py")
+    f0 = o.fin.copy()
+    o.step(40)
+    assert np.array_equal(o.fin[3, N - 2, :], f0[3, N - 2, :])
+    assert np.array_equal(o.fin[6, N - 2, :N - 1], f0[6, N - 2, :N - 1])   # row Y-1: bottom rule writes f6
+    assert np.array_equal(o.fin[7, N - 2, 1:], f0[7, N - 2, 1:])           # row 0: lid rule writes f7
+    assert np.array_equal(o.fin[2, :, N - 2], f0[2, :, N - 2])
+    assert np.array_equal(o.fin[1, N - 1, :], f0[1, N - 1, :])
+    assert np.array_equal(o.fin[4, :, N - 1], f0[4, :, N - 1])
+    assert not np.array_equal(o.fin[1, N // 2, :], f0[1, N // 2, :])
+
+
+def test_recorded_cross_check_c1():
+    """C1 of BASELINE.json (128^2, Re = 100, 1000 steps, fp64, MRT.py semantics) against the
+    values RECORDED in SURVEY.md Appendix C (provenance: see the JSON's _provenance field)."""
+    rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
+    o = on.CavityOracle(128, 128, 100.0, semantics="mrt_py", collision="SRT").step(1000)
+    uLB = 0.08
+    for y, v in zip(rec["ux_mid_column"]["y"], rec["ux_mid_column"]["value_over_uLB"]):
+        assert o.u[0, 64, y] / uLB == pytest.approx(v, rel=1e-12, abs=1e-15)
+    for x, v in zip(rec["uy_mid_row"]["x"], rec["uy_mid_row"]["value_over_uLB"]):
+        assert o.u[1, x, 64] / uLB == pytest.approx(v, rel=1e-12, abs=1e-15)
+    assert o.rho.mean() == pytest.approx(rec["rho"]["mean"], rel=1e-13)
+    assert o.rho.min() == pytest.approx(rec["rho"]["min"], rel=1e-13)
+    assert o.rho.max() == pytest.approx(rec["rho"]["max"], rel=1e-13)
+    assert o.fin.sum() == pytest.approx(rec["sum_fin"], rel=1e-12)
+    # digests are platform/NumPy-version dependent: informative only
+    same = all(hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == rec["sha256"][n]
+               for n, a in (("u", o.u), ("rho", o.rho), ("fin", o.fin)))
+    if not same:
+        pytest.skip("floating values match the record; byte digests differ on this platform")
+
+
+@pytest.mark.parametrize("sem,coll", [("mrt_gpu", "MRT"), ("mrt_gpu", "SRT"), ("mrt_py", "SRT")])
+def test_physics_pin_against_ghia_re100(sem, coll):
+    """Physics-level pin against the reference's own data file: converged Re = 100 centrelines
+    on a 64^2 lattice agree with Ghia et al. to a few 1e-2 of the lid speed."""
+    from latticeboltzmannsimulations_amd import ghia
+    set_threads(min(8, max_threads()))
+    try:
+        o = CavityOracleC(64, 64, 100.0, semantics=sem, collision=coll)
+        prev = None
+        for _ in range(12):
+            o.step(2000)
+            m = float(np.mean(o.u))
+            if prev is not None and abs(m - prev) / 0.08 < 1e-7:
+                break
+            prev = m
+    finally:
+        set_threads(1)
+    assert np.isfinite(o.fin).all()
+    ex, ey = ghia.profile_errors(o.u, 100, 0.08)
+    assert ex < 0.06 and ey < 0.06, (ex, ey)
+    assert ghia.r2_value(o.u, 100, 0.08) > 0.9
