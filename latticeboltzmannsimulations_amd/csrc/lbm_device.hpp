@@ -270,4 +270,74 @@ __device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Vector path (MRT_GPU.py semantics only): a thread owns V consecutive cells of one row and
+// moves 16 bytes per direction plane per access.  Rows on the lid / bottom wall are handed
+// to update_cell (wall rules, kept slots, parked densities); on every other row the only
+// wall cells are x = 0 and x = X-1, where MRT_GPU.py:674-682 reduces exactly to copying
+// the opposite population: fe_a - fe_b is +0 for a resting wall (same weight, u = 0), so
+// f_a = 0 + f_b.  Arithmetic per cell is the same sequence of IEEE operations as update_cell.
+// ------------------------------------------------------------------------------------------
+template <typename R, int V>
+struct VecT {
+    typedef R type __attribute__((ext_vector_type(V)));
+};
+
+template <typename R, int V, bool NT>
+__device__ __forceinline__ typename VecT<R, V>::type vload(const R* p, bool aligned) {
+    typedef typename VecT<R, V>::type T;
+    if (aligned) {
+        if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
+        return *reinterpret_cast<const T*>(p);
+    }
+    T t;   // element-aligned only (x -+ 1 neighbours): one unaligned 16-byte global load
+    __builtin_memcpy(&t, p, sizeof(T));
+    return t;
+}
+
+template <typename R, int V, bool NT>
+__device__ __forceinline__ void vstore(R* p, typename VecT<R, V>::type v) {
+    typedef typename VecT<R, V>::type T;
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+    else *reinterpret_cast<T*>(p) = v;
+}
+
+template <typename R, int COLL, int V, bool NT>
+__device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
+                                           const Relax<R>& w, int raw, int x0, int y) {
+    typedef typename VecT<R, V>::type T;
+    const int X = geo.nx;
+    T in[Q], outv[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int cx = raw ? 0 : cxk(k), cy = raw ? 0 : cyk(k);
+        in[k] = vload<R, V, NT>(src + k * geo.plane + geo.at(x0 - cx, y + cy), cxk(k) == 0 || raw);
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+        const int x = x0 + c;
+        R g[Q], out[Q], fe[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) g[k] = in[k][c];
+        const bool left = (c == 0) && (x == 0), right = (c == V - 1) && (x == X - 1);
+        if (!raw) {
+            if (left) { g[1] = (R)0 + g[3]; g[5] = (R)0 + g[7]; g[8] = (R)0 + g[6]; }
+            if (right) { g[3] = (R)0 + g[1]; g[6] = (R)0 + g[8]; g[7] = (R)0 + g[5]; }
+        }
+        R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+        if (COLL != C_MRT) {   // the MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
+            R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
+            R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
+            if (left || right) { ux = (R)0; uy = (R)0; }
+            equ<R>(rho, ux, uy, fe);
+        }
+        collide<R, COLL>(g, rho, fe, w, out);
+#pragma unroll
+        for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
+    }
+    const long long me = geo.at(x0, y);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) vstore<R, V, NT>(dst + k * geo.plane + me, outv[k]);
+}
+
 }  // namespace lbm

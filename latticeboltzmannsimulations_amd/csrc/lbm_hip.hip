@@ -31,6 +31,28 @@ __global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src,
     update_cell<R, COLL, SEM>(src, dst, geo, w, raw, x, y);
 }
 
+// Vector fused step (MRT_GPU.py semantics): 1-D grid of nrows * nxb blocks; a block owns
+// BLK * V consecutive cells of one row.  Blocks are dealt round-robin to the 8 XCDs, so block
+// b is remapped such that every XCD walks its own contiguous band of rows (measured +5 % on
+// the 18-stream access pattern; speed only, any placement is correct).
+template <typename R, int COLL, int V, bool NT>
+__global__ __launch_bounds__(BLK) void k_step_vec(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+                                                  int raw, int row0, int row_stride, int nxb, int nblocks) {
+    int b = blockIdx.x;
+    const int per = nblocks >> 3;
+    if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
+    const int y = row0 + (b / nxb) * row_stride;
+    const int x0 = ((b % nxb) * BLK + threadIdx.x) * V;
+    if (x0 >= geo.nx) return;
+    const int gy = geo.y0 + y;
+    if (gy == 0 || gy == geo.NY - 1) {
+#pragma unroll 1
+        for (int c = 0; c < V; ++c) update_cell<R, COLL, SEM_GPU>(src, dst, geo, w, raw, x0 + c, y);
+    } else {
+        update_vec<R, COLL, V, NT>(src, dst, geo, w, raw, x0, y);
+    }
+}
+
 // init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
 template <typename R>
 __global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB) {
@@ -110,6 +132,8 @@ struct lbm_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
+    bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
+    bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     std::string err;
 };
 
@@ -191,6 +215,18 @@ template <typename R, int COLL, int SEM>
 void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
     const R* src = (const R*)c->lat[c->cur];
     R* dst = (R*)c->lat[c->cur ^ 1];
+    if (SEM == SEM_GPU && c->use_vec) {
+        constexpr int V = 16 / (int)sizeof(R);
+        const int nxb = (c->geo.nx / V + BLK - 1) / BLK;
+        const int nblocks = nxb * nrows;
+        if (c->use_nt)
+            hipLaunchKernelGGL((k_step_vec<R, COLL, V, true>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
+                               relax_of<R>(c->p), c->raw[c->cur], row0, stride, nxb, nblocks);
+        else
+            hipLaunchKernelGGL((k_step_vec<R, COLL, V, false>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
+                               relax_of<R>(c->p), c->raw[c->cur], row0, stride, nxb, nblocks);
+        return;
+    }
     hipLaunchKernelGGL((k_step_generic<R, COLL, SEM>), grid_rows(c, nrows), dim3(BLK), 0, s, src, dst, c->geo,
                        relax_of<R>(c->p), c->raw[c->cur], row0, stride);
 }
@@ -442,6 +478,14 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     c->geo.pitch = ((p->nx + 2 * GH) + 3) / 4 * 4;
     c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2);
     const size_t bytes = (size_t)Q * c->geo.plane * c->es;
+    {
+        const int V = 16 / c->es;
+        const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;
+        if (p->kernel == LBM_KERNEL_VEC && !can_vec) return (delete c, bail("kernel = VEC needs MRT_GPU semantics and nx % (16 / sizeof(real)) == 0"));
+        c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC;
+        const char* nt = std::getenv("LBM_NT");
+        c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
+    }
     auto cleanup = [&](const std::string& m) -> lbm_ctx* { lbm_destroy(c); return bail(m); };
     if ((e = hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
     if ((e = hipStreamCreateWithFlags(&c->s_comm, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
