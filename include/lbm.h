@@ -38,6 +38,7 @@ enum { LBM_SRT = 0, LBM_TRT = 1, LBM_MRT = 2 };         /* RT = 'SRT' | 'TRT' | 
 enum { LBM_SEM_MRT_PY = 0, LBM_SEM_MRT_GPU = 1 };       /* streaming windows + wall rules of MRT.py:404-453
                                                            or of MRT_GPU.py:412,674-692 */
 enum { LBM_KERNEL_AUTO = 0, LBM_KERNEL_GENERIC = 1, LBM_KERNEL_VEC = 2 }; /* fused pull kernel variant */
+enum { LBM_LAYOUT_AUTO = 0, LBM_LAYOUT_PLANES = 1, LBM_LAYOUT_ROWS = 2 }; /* device arrays: [k][y][x] or [y][k][x] */
 enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour towards smaller / larger y */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
@@ -55,7 +56,7 @@ typedef struct lbm_params {
     int32_t kernel;      /* LBM_KERNEL_* */
     int32_t turb;        /* must be 0 (Smagorinsky closure, MRT_GPU.py:368-387, not built yet) */
     int32_t device;      /* HIP device ordinal (reference: cuda.Device(0), MRT_GPU.py:29) */
-    int32_t reserved;
+    int32_t layout;      /* LBM_LAYOUT_* (device-side only; host arrays are unaffected) */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */
     double omega;        /* = omegap = omega_nu, MRT_GPU.py:65 */
     double omegam;       /* TRT, MRT_GPU.py:80 */

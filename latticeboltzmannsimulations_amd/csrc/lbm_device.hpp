@@ -195,13 +195,19 @@ __device__ __forceinline__ void wall_rules(R (&g)[Q], const R (&fe)[Q], int x, i
     }
 }
 
-// Addressing of one padded plane set.  Local row y in [-1, ny], column x in [-GH, nx+GH).
+// Addressing of the nine direction arrays.  Local row y in [-1, ny], column x in [-GH, nx+GH).
+// Element (k, x, y) lives at k * plane + at(x, y).  Two layouts share this formula:
+//   planes  [k][y][x]: plane = pitch * (ny + 2), row = pitch       (nine separate arrays)
+//   rows    [y][k][x]: plane = pitch,            row = 9 * pitch   (the nine rows y of the nine
+//                                                                   directions are adjacent)
+// Every row of every direction is contiguous and 16-byte aligned in both.
 struct Geo {
-    long long plane;  // elements between consecutive direction planes
+    long long plane;  // elements between the same cell of consecutive directions
+    long long row;    // elements between consecutive rows of one direction
     int pitch;        // elements per row (nx + 2*GH, multiple of 4)
     int nx, ny;       // columns, local rows
     int y0, NY;       // first global row of this slab, global height
-    __host__ __device__ __forceinline__ long long at(int x, int y) const { return (long long)(y + 1) * pitch + GH + x; }
+    __host__ __device__ __forceinline__ long long at(int x, int y) const { return (long long)(y + 1) * row + GH + x; }
 };
 
 // Where a perimeter cell parks the density of its last macroscopic state: slot 0 of the

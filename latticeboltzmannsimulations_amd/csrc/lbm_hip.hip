@@ -461,6 +461,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return bail("bad semantics");
     if (p->turb != 0) return bail("turb = 1 (Smagorinsky) is not implemented");
     if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_VEC) return bail("bad kernel variant");
+    if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return bail(std::string("no HIP device: ") + hipGetErrorString(e));
@@ -476,8 +477,14 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     c->geo.y0 = p->y0;
     c->geo.NY = p->ny;
     c->geo.pitch = ((p->nx + 2 * GH) + 3) / 4 * 4;
-    c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2);
-    const size_t bytes = (size_t)Q * c->geo.plane * c->es;
+    if (p->layout == LBM_LAYOUT_PLANES) {
+        c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2);
+        c->geo.row = c->geo.pitch;
+    } else {  // LBM_LAYOUT_ROWS (default): +10 % on the 18-stream pattern, see DESIGN.md
+        c->geo.plane = c->geo.pitch;
+        c->geo.row = (long long)Q * c->geo.pitch;
+    }
+    const size_t bytes = (size_t)Q * c->geo.pitch * (p->ny_local + 2) * c->es;
     {
         const int V = 16 / c->es;
         const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;

@@ -12,6 +12,7 @@ _DT = {np.dtype(np.float32): L.LBM_F32, np.dtype(np.float64): L.LBM_F64}
 _COLL = {"SRT": L.LBM_SRT, "TRT": L.LBM_TRT, "MRT": L.LBM_MRT}
 _SEM = {"mrt_py": L.LBM_SEM_MRT_PY, "mrt_gpu": L.LBM_SEM_MRT_GPU}
 _KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC}
+_LAYOUT = {"auto": L.LBM_LAYOUT_AUTO, "planes": L.LBM_LAYOUT_PLANES, "rows": L.LBM_LAYOUT_ROWS}
 
 
 def relaxation(Re, ysize, uLB=0.08, omega_eps=1.2, omega_q=1.2):
@@ -35,10 +36,12 @@ class CavitySolver:
                    or 'mrt_py' (the CPU script's windows and wall rules, MRT.py:404-453)
     dtype        : float32 (what MRT_GPU.py stores, MRT_GPU.py:207) or float64 (what MRT.py computes in)
     rows         : (y0, ny_local) when this object holds only a slab
+    kernel       : 'auto' | 'generic' (one thread per cell) | 'vec' (16 B per access, MRT_GPU.py semantics)
+    layout       : device arrays 'planes' [k][y][x], 'rows' [y][k][x], 'auto' (= rows)
     """
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,
-                 device=0, rows=None, kernel="auto", omega_eps=None, omega_q=None):
+                 device=0, rows=None, kernel="auto", layout="auto", omega_eps=None, omega_q=None):
         self._h = None
         self.lib = L.lib()
         self.nx, self.ny = int(xsize), int(ysize)
@@ -61,6 +64,7 @@ class CavitySolver:
         p.nx, p.ny, p.y0, p.ny_local = self.nx, self.ny, self.y0, self.ny_local
         p.dtype, p.collision, p.semantics = _DT[self.dtype], _COLL[RT], _SEM[semantics]
         p.kernel, p.turb, p.device = _KERNEL[kernel], int(turb), int(device)
+        p.layout = _LAYOUT[layout]
         p.uLB = self.uLB
         p.omega, p.omegam = self.relax["omega"], self.relax["omegam"]
         p.omega_e, p.omega_eps, p.omega_q = self.relax["omega_e"], self.relax["omega_eps"], self.relax["omega_q"]

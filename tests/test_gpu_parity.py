@@ -47,6 +47,22 @@ def test_hip_step_is_bit_identical_to_oracle(kernel, sem, coll, dtype):
             assert s.steps_done == 100
 
 
+@pytest.mark.parametrize("layout", ["planes", "rows"])
+@pytest.mark.parametrize("kernel", ["generic", "vec"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_device_layouts_give_identical_results(layout, kernel, dtype):
+    nx, ny = 260, 37
+    o = CavityOracleC(nx, ny, 400.0, semantics="mrt_gpu", collision="MRT", dtype=dtype).step(60)
+    with CavitySolver(nx, ny, 400.0, RT="MRT", dtype=dtype, kernel=kernel, layout=layout) as s:
+        s.step(60)
+        same(s, o, f"layout={layout} kernel={kernel}")
+    if kernel == "generic":
+        o = CavityOracleC(nx, ny, 400.0, semantics="mrt_py", collision="SRT", dtype=dtype).step(60)
+        with CavitySolver(nx, ny, 400.0, RT="SRT", semantics="mrt_py", dtype=dtype, layout=layout) as s:
+            s.step(60)
+            same(s, o, f"mrt_py layout={layout}")
+
+
 def test_config_c1_128_re100_1000_steps():
     """BASELINE.json configs[0]: 128x128, Re = 100, fp64, 1000 steps, MRT.py semantics."""
     rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
