@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "liblbm_hip.so")
+LIB_PATH = os.environ.get("LBM_LIB_PATH", os.path.join(_HERE, "liblbm_hip.so"))   # override: A/B builds of the kernels
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "lbm.h")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -35,8 +35,11 @@ __global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src,
 // BLK * V consecutive cells of one row.  Blocks are dealt round-robin to the 8 XCDs, so block
 // b is remapped such that every XCD walks its own contiguous band of rows (measured +5 % on
 // the 18-stream access pattern; speed only, any placement is correct).
+#ifndef LBM_VEC_MIN_WAVES
+#define LBM_VEC_MIN_WAVES 1
+#endif
 template <typename R, int COLL, int V, bool NT>
-__global__ __launch_bounds__(BLK) void k_step_vec(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+__global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                   int raw, int row0, int row_stride, int nxb, int nblocks) {
     int b = blockIdx.x;
     const int per = nblocks >> 3;
@@ -495,7 +498,12 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     }
     auto cleanup = [&](const std::string& m) -> lbm_ctx* { lbm_destroy(c); return bail(m); };
     if ((e = hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
-    if ((e = hipStreamCreateWithFlags(&c->s_comm, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
+    {   // halo exchange stream at the highest priority: its (tiny) RCCL kernels must not queue behind the
+        // thousands of workgroups of the interior kernel they are meant to overlap
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if ((e = hipStreamCreateWithPriority(&c->s_comm, hipStreamNonBlocking, hi)) != hipSuccess) return cleanup("hipStreamCreate");
+    }
     if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");

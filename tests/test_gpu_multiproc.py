@@ -1,0 +1,63 @@
+"""Two and three PROCESSES sharing the one GPU of the test box, one y-slab each, halos moved by
+torch.distributed over gloo through host buffers (lbm_halo_export / lbm_halo_import): the slab
+kernels, ghost-row conventions and the HaloDriver under real multi-process conditions.  The RCCL
+transport itself needs >= 2 GPUs and is exercised by `bench.py --gpus N` on a multi-GPU node."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, nx, ny, steps, sem, coll, dtype, q):
+    import torch.distributed as dist
+    from latticeboltzmannsimulations_amd import CavitySolver
+    from latticeboltzmannsimulations_amd.slab import HaloDriver, partition_rows
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        rows = partition_rows(ny, world)[rank]
+        with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=np.dtype(dtype), rows=rows) as s:
+            HaloDriver(s, rank, world, device="cpu").step(steps)
+            u = np.zeros((2, nx, ny), dtype=dtype); rho = np.zeros((nx, ny), dtype=dtype); fin = np.zeros((9, nx, ny), dtype=dtype)
+            s.get_fields(u=u, rho=rho, fin=fin)
+        y0, n = rows
+        q.put((rank, y0, n, u[:, :, y0:y0 + n].copy(), rho[:, y0:y0 + n].copy(), fin[:, :, y0:y0 + n].copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sem,coll,dtype", [(2, "mrt_gpu", "MRT", "float32"), (3, "mrt_py", "SRT", "float64")])
+def test_slab_per_process_over_gloo_equals_single_lattice(world, sem, coll, dtype):
+    import torch.multiprocessing as mp
+    from latticeboltzmannsimulations_amd import CavitySolver
+    nx, ny, steps = 256, 90, 30
+    with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=np.dtype(dtype)) as one:
+        one.step(steps)
+        u1, r1, f1 = one.get_fields(want_fin=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ny, steps, sem, coll, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    u = np.concatenate([g[3] for g in got], axis=2)
+    rho = np.concatenate([g[4] for g in got], axis=1)
+    fin = np.concatenate([g[5] for g in got], axis=2)
+    assert np.array_equal(fin, f1) and np.array_equal(u, u1) and np.array_equal(rho, r1)
