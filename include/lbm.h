@@ -54,7 +54,7 @@ typedef struct lbm_params {
     int32_t collision;   /* LBM_SRT | LBM_TRT | LBM_MRT */
     int32_t semantics;   /* LBM_SEM_MRT_PY | LBM_SEM_MRT_GPU */
     int32_t kernel;      /* LBM_KERNEL_* */
-    int32_t turb;        /* must be 0 (Smagorinsky closure, MRT_GPU.py:368-387, not built yet) */
+    int32_t turb;        /* 0 | 1: Smagorinsky closure of MRT_GPU.py:368-387 (MRT_GPU semantics only) */
     int32_t device;      /* HIP device ordinal (reference: cuda.Device(0), MRT_GPU.py:29) */
     int32_t layout;      /* LBM_LAYOUT_* (device-side only; host arrays are unaffected) */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */

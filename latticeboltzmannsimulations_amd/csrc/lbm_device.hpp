@@ -153,6 +153,30 @@ __device__ __forceinline__ void collide(const R (&f)[Q], R rho, const R (&feq)[Q
     }
 }
 
+// Smagorinsky sub-grid closure, MRT_GPU.py:368-387 (turb = 1).  The Van Driest lines 370-373 are
+// dead code (Cs2 is overwritten by 0.025 at line 374).  The reference reads, per cell, the
+// equilibrium and the density that funRT wrote in the PREVIOUS step; only sum_k cx cy feq_k of it
+// is used, so the history kept per cell is two reals: planes Q (that sum) and Q + 1 (density).
+constexpr int K_QEQ = Q;      // plane index of  -feq8 + (feq7 + (-feq6 + feq5))  of the previous step
+constexpr int K_RHO = Q + 1;  // plane index of the previous step's density (after the lid override)
+
+template <typename R>
+__device__ __forceinline__ R diag_flux(const R (&f)[Q]) {   // product = cx cy f_k + product, k = 0..8
+    return -f[8] + (f[7] + (-f[6] + f[5]));
+}
+__device__ __forceinline__ float real_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double real_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float real_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double real_abs(double x) { return fabs(x); }
+
+template <typename R>
+__device__ __forceinline__ R smagorinsky_omega(const R (&f)[Q], R qeq_prev, R rho_prev, R omega) {
+    const R tau0 = (R)1.0 / omega;
+    const R q = diag_flux<R>(f) - qeq_prev;
+    const R tau = (R)0.5 * (tau0 + real_sqrt(tau0 * tau0 + (((R)(18 * 1.4142) * (R)0.025) * real_abs(q)) / rho_prev));
+    return (R)1.0 / tau;
+}
+
 // a8: wall rules on the populations of ONE perimeter cell, given the equilibrium of the
 // previous macroscopic state of that cell.  SEM_PY: MRT.py:450-453 in statement order
 // (left equilibrium, right mirror pairing, bottom, lid); SEM_GPU: MRT_GPU.py:674-692
@@ -241,12 +265,12 @@ __device__ __forceinline__ void gather(const R* __restrict__ src, const Geo& geo
 }
 
 // One fused update of cell (x, y): gather -> (kept slots) -> moments -> collide -> store.
-template <typename R, int COLL, int SEM>
+template <typename R, int COLL, int SEM, bool TURB = false>
 __device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
-                                            const Relax<R>& w, int raw, int x, int y) {
+                                            const Relax<R>& w0, int raw, int x, int y) {
     const int X = geo.nx, Y = geo.NY, gy = geo.y0 + y;
     R g[Q];
-    gather<R, SEM>(src, geo, raw, w.uLB, x, y, g);
+    gather<R, SEM>(src, geo, raw, w0.uLB, x, y, g);
     // kept slots: a slot outside its streaming window keeps its value; park it where the
     // next pull of this cell will look for it.
     const bool near_edge = (x <= 0) || (x >= X - 2) || (gy <= 0) || (gy >= Y - 2);
@@ -256,10 +280,16 @@ __device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __rest
             if (!in_window<SEM>(k, x, gy, X, Y)) dst[k * geo.plane + geo.at(x - cxk(k), y + cyk(k))] = g[k];
     }
     R rho, ux, uy, fe[Q], out[Q];
+    const long long me = geo.at(x, y);
+    Relax<R> w = w0;
+    if (TURB) w.w_nu = smagorinsky_omega<R>(g, src[K_QEQ * geo.plane + me], src[K_RHO * geo.plane + me], w0.w_nu);
     macros<R>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
     equ<R>(rho, ux, uy, fe);
     collide<R, COLL>(g, rho, fe, w, out);
-    const long long me = geo.at(x, y);
+    if (TURB) {
+        dst[K_QEQ * geo.plane + me] = diag_flux<R>(fe);
+        dst[K_RHO * geo.plane + me] = rho;
+    }
     if (!near_edge) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) dst[k * geo.plane + me] = out[k];
@@ -308,12 +338,17 @@ __device__ __forceinline__ void vstore(R* p, typename VecT<R, V>::type v) {
     else *reinterpret_cast<T*>(p) = v;
 }
 
-template <typename R, int COLL, int V, bool NT>
+template <typename R, int COLL, int V, bool NT, bool TURB = false>
 __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
-                                           const Relax<R>& w, int raw, int x0, int y) {
+                                           const Relax<R>& w0, int raw, int x0, int y) {
     typedef typename VecT<R, V>::type T;
     const int X = geo.nx;
-    T in[Q], outv[Q];
+    const long long me = geo.at(x0, y);
+    T in[Q], outv[Q], hq, hr;
+    if (TURB) {
+        hq = vload<R, V, NT>(src + K_QEQ * geo.plane + me, true);
+        hr = vload<R, V, NT>(src + K_RHO * geo.plane + me, true);
+    }
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
         const int cx = raw ? 0 : cxk(k), cy = raw ? 0 : cyk(k);
@@ -330,8 +365,10 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
             if (left) { g[1] = (R)0 + g[3]; g[5] = (R)0 + g[7]; g[8] = (R)0 + g[6]; }
             if (right) { g[3] = (R)0 + g[1]; g[6] = (R)0 + g[8]; g[7] = (R)0 + g[5]; }
         }
+        Relax<R> w = w0;
+        if (TURB) w.w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
         R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
-        if (COLL != C_MRT) {   // the MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
+        if (COLL != C_MRT || TURB) {   // the plain MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
             R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
             R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
             if (left || right) { ux = (R)0; uy = (R)0; }
@@ -340,10 +377,14 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
         collide<R, COLL>(g, rho, fe, w, out);
 #pragma unroll
         for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
+        if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
     }
-    const long long me = geo.at(x0, y);
 #pragma unroll
     for (int k = 0; k < Q; ++k) vstore<R, V, NT>(dst + k * geo.plane + me, outv[k]);
+    if (TURB) {
+        vstore<R, V, NT>(dst + K_QEQ * geo.plane + me, hq);
+        vstore<R, V, NT>(dst + K_RHO * geo.plane + me, hr);
+    }
 }
 
 }  // namespace lbm

@@ -22,13 +22,13 @@ using namespace lbm;
 constexpr int BLK = 256;
 
 // Generic fused step: one thread per cell, rows y = row0 + blockIdx.y * row_stride.
-template <typename R, int COLL, int SEM>
+template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src, R* __restrict__ dst, Geo geo,
                                                       Relax<R> w, int raw, int row0, int row_stride) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = row0 + blockIdx.y * row_stride;
     if (x >= geo.nx) return;
-    update_cell<R, COLL, SEM>(src, dst, geo, w, raw, x, y);
+    update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, raw, x, y);
 }
 
 // Vector fused step (MRT_GPU.py semantics): 1-D grid of nrows * nxb blocks; a block owns
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src,
 #ifndef LBM_VEC_MIN_WAVES
 #define LBM_VEC_MIN_WAVES 1
 #endif
-template <typename R, int COLL, int V, bool NT>
+template <typename R, int COLL, int V, bool NT, bool TURB>
 __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                   int raw, int row0, int row_stride, int nxb, int nblocks) {
     int b = blockIdx.x;
@@ -50,15 +50,15 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
     const int gy = geo.y0 + y;
     if (gy == 0 || gy == geo.NY - 1) {
 #pragma unroll 1
-        for (int c = 0; c < V; ++c) update_cell<R, COLL, SEM_GPU>(src, dst, geo, w, raw, x0 + c, y);
+        for (int c = 0; c < V; ++c) update_cell<R, COLL, SEM_GPU, TURB>(src, dst, geo, w, raw, x0 + c, y);
     } else {
-        update_vec<R, COLL, V, NT>(src, dst, geo, w, raw, x0, y);
+        update_vec<R, COLL, V, NT, TURB>(src, dst, geo, w, raw, x0, y);
     }
 }
 
 // init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
 template <typename R>
-__global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB) {
+__global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB, int turb) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= geo.nx) return;
@@ -66,17 +66,32 @@ __global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uL
     equ<R>((R)1, (geo.y0 + y) == 0 ? uLB : (R)0, (R)0, fe);
 #pragma unroll
     for (int k = 0; k < Q; ++k) lat[k * geo.plane + geo.at(x, y)] = fe[k];
+    if (turb) {   // Smagorinsky history: feq_g starts as a copy of fin, rho_g as 1 (MRT_GPU.py:324-326)
+        lat[K_QEQ * geo.plane + geo.at(x, y)] = diag_flux<R>(fe);
+        lat[K_RHO * geo.plane + geo.at(x, y)] = (R)1;
+    }
 }
 
 // staging (reference host layout, [9][nx][ny_local], y fastest) -> raw lattice
 template <typename R>
-__global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* __restrict__ lat, Geo geo) {
+__global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* __restrict__ lat, Geo geo, R uLB, int turb) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= geo.nx) return;
     const long long n = (long long)geo.nx * geo.ny;
+    R g[Q];
 #pragma unroll
-    for (int k = 0; k < Q; ++k) lat[k * geo.plane + geo.at(x, y)] = stage[k * n + (long long)x * geo.ny + y];
+    for (int k = 0; k < Q; ++k) {
+        g[k] = stage[k * n + (long long)x * geo.ny + y];
+        lat[k * geo.plane + geo.at(x, y)] = g[k];
+    }
+    if (turb) {   // history := equilibrium / density of the uploaded state (there is no "previous step")
+        R rho, ux, uy, fe[Q];
+        macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
+        equ<R>(rho, ux, uy, fe);
+        lat[K_QEQ * geo.plane + geo.at(x, y)] = diag_flux<R>(fe);
+        lat[K_RHO * geo.plane + geo.at(x, y)] = rho;
+    }
 }
 
 // lattice -> staging: current populations (post stream + wall rules) in host layout
@@ -214,7 +229,7 @@ Relax<R> relax_of(const lbm_params& p) {
 dim3 grid_rows(const lbm_ctx* c, int nrows) { return dim3((c->geo.nx + BLK - 1) / BLK, nrows, 1); }
 
 // launch the fused step on rows row0 + i*stride, i in [0, nrows)
-template <typename R, int COLL, int SEM>
+template <typename R, int COLL, int SEM, bool TURB>
 void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
     const R* src = (const R*)c->lat[c->cur];
     R* dst = (R*)c->lat[c->cur ^ 1];
@@ -223,21 +238,22 @@ void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
         const int nxb = (c->geo.nx / V + BLK - 1) / BLK;
         const int nblocks = nxb * nrows;
         if (c->use_nt)
-            hipLaunchKernelGGL((k_step_vec<R, COLL, V, true>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
+            hipLaunchKernelGGL((k_step_vec<R, COLL, V, true, TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
                                relax_of<R>(c->p), c->raw[c->cur], row0, stride, nxb, nblocks);
         else
-            hipLaunchKernelGGL((k_step_vec<R, COLL, V, false>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
+            hipLaunchKernelGGL((k_step_vec<R, COLL, V, false, TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
                                relax_of<R>(c->p), c->raw[c->cur], row0, stride, nxb, nblocks);
         return;
     }
-    hipLaunchKernelGGL((k_step_generic<R, COLL, SEM>), grid_rows(c, nrows), dim3(BLK), 0, s, src, dst, c->geo,
+    hipLaunchKernelGGL((k_step_generic<R, COLL, SEM, TURB>), grid_rows(c, nrows), dim3(BLK), 0, s, src, dst, c->geo,
                        relax_of<R>(c->p), c->raw[c->cur], row0, stride);
 }
 
 template <typename R, int COLL>
 void launch_step_c(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
-    if (c->p.semantics == LBM_SEM_MRT_PY) launch_step_t<R, COLL, SEM_PY>(c, row0, stride, nrows, s);
-    else launch_step_t<R, COLL, SEM_GPU>(c, row0, stride, nrows, s);
+    if (c->p.semantics == LBM_SEM_MRT_PY) launch_step_t<R, COLL, SEM_PY, false>(c, row0, stride, nrows, s);
+    else if (c->p.turb) launch_step_t<R, COLL, SEM_GPU, true>(c, row0, stride, nrows, s);
+    else launch_step_t<R, COLL, SEM_GPU, false>(c, row0, stride, nrows, s);
 }
 
 template <typename R>
@@ -462,7 +478,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->dtype != LBM_F32 && p->dtype != LBM_F64) return bail("dtype must be LBM_F32 or LBM_F64");
     if (p->collision < LBM_SRT || p->collision > LBM_MRT) return bail("collision must be SRT, TRT or MRT");
     if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return bail("bad semantics");
-    if (p->turb != 0) return bail("turb = 1 (Smagorinsky) is not implemented");
+    if (p->turb != 0 && p->turb != 1) return bail("turb must be 0 or 1");
+    if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return bail("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
     if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_VEC) return bail("bad kernel variant");
     if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
     int ndev = 0;
@@ -480,14 +497,15 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     c->geo.y0 = p->y0;
     c->geo.NY = p->ny;
     c->geo.pitch = ((p->nx + 2 * GH) + 3) / 4 * 4;
+    const int nplanes = p->turb ? Q + 2 : Q;   // + the two Smagorinsky history planes
     if (p->layout == LBM_LAYOUT_PLANES) {
         c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2);
         c->geo.row = c->geo.pitch;
     } else {  // LBM_LAYOUT_ROWS (default): +10 % on the 18-stream pattern, see DESIGN.md
         c->geo.plane = c->geo.pitch;
-        c->geo.row = (long long)Q * c->geo.pitch;
+        c->geo.row = (long long)nplanes * c->geo.pitch;
     }
-    const size_t bytes = (size_t)Q * c->geo.pitch * (p->ny_local + 2) * c->es;
+    const size_t bytes = (size_t)nplanes * c->geo.pitch * (p->ny_local + 2) * c->es;
     {
         const int V = 16 / c->es;
         const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;
@@ -545,9 +563,9 @@ int lbm_init_equilibrium(lbm_ctx* c) {
     c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
-        hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB);
+        hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb);
     else
-        hipLaunchKernelGGL((k_init<double>), g, dim3(BLK), 0, c->s_compute, (double*)c->lat[0], c->geo, (double)c->p.uLB);
+        hipLaunchKernelGGL((k_init<double>), g, dim3(BLK), 0, c->s_compute, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb);
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
 }
@@ -564,9 +582,9 @@ int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
     c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
-        hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo);
+        hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb);
     else
-        hipLaunchKernelGGL((k_import<double>), g, dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo);
+        hipLaunchKernelGGL((k_import<double>), g, dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->s_compute));
     return LBM_OK;

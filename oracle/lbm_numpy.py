@@ -89,8 +89,10 @@ class CavityOracle:
     """Whole-domain stepper on reference-layout arrays fin[9, X, Y]."""
 
     def __init__(self, nx, ny, Re, uLB=0.08, semantics="mrt_py", collision="SRT",
-                 dtype=np.float64, omega_eps=None, omega_q=None, ny_global=None):
+                 dtype=np.float64, omega_eps=None, omega_q=None, ny_global=None, turb=0):
         assert semantics in ("mrt_py", "mrt_gpu") and collision in ("SRT", "TRT", "MRT")
+        assert not (turb and semantics == "mrt_py"), "the Smagorinsky closure exists only in MRT_GPU.py"
+        self.turb = int(turb)
         self.nx, self.ny, self.uLB = nx, ny, uLB
         self.sem, self.coll = semantics, collision
         self.dtype = np.dtype(dtype)
@@ -111,7 +113,7 @@ class CavityOracle:
         iv = np.zeros((2, nx, ny), dtype=dtype)
         iv[0, :, 0] = uLB
         self.fin = equ(self.rho, iv[0], iv[1], self.t)
-        self.feq = self.fin.copy()
+        self.feq = self.fin.copy()          # feq_g starts as a copy of fin (MRT_GPU.py:325)
         self.fpost = self.fin.copy()
         self.nsteps = 0
 
@@ -130,14 +132,28 @@ class CavityOracle:
         ux[:, 0] = R(self.uLB); uy[:, 0] = 0                               # MRT.py:342
         return rho, ux, uy
 
+    # --- Smagorinsky relaxation rate (MRT_GPU.py:368-387; the Van Driest lines 370-373 are dead
+    #     code because Cs2 is overwritten at 374) ------------------------------------------
+    def smagorinsky_omega(self, f, feq_prev, rho_prev):
+        R = self.R
+        tau0 = R(1.0) / R(self.relax["omega"])
+        # product = c_x c_y f_k + product, k = 0..8: only the diagonals contribute
+        p1 = -f[8] + (f[7] + (-f[6] + f[5]))
+        p2 = -feq_prev[8] + (feq_prev[7] + (-feq_prev[6] + feq_prev[5]))
+        q = p1 - p2
+        tau = R(0.5) * (tau0 + np.sqrt(tau0 * tau0 + ((R(18 * 1.4142) * R(0.025)) * np.abs(q)) / rho_prev))
+        return R(1.0) / tau
+
     # --- a6: collision operators -------------------------------------------------------
-    def collide(self, f, rho, feq):
+    def collide(self, f, rho, feq, w_nu=None):
         R = self.R
         rl = self.relax
+        if w_nu is None:
+            w_nu = R(rl["omega"])
         if self.coll == "SRT":                                             # MRT.py:396 / MRT_GPU.py:413
-            return f - R(rl["omega"]) * (f - feq)
+            return f - w_nu * (f - feq)
         if self.coll == "TRT":                                             # MRT_GPU.py:455-462,514-525
-            op, om = R(rl["omega"]), R(rl["omegam"])
+            op, om = w_nu, R(rl["omegam"])
             fp = np.empty_like(f); fm = np.empty_like(f)
             ep = np.empty_like(f); em = np.empty_like(f)
             for a, b in ((2, 4), (5, 7), (6, 8), (1, 3)):
@@ -169,8 +185,10 @@ class CavityOracle:
         meq[6] = -jy + R(3.0) * ((jy * jy) * jy)
         meq[7] = jx * jx - jy * jy
         meq[8] = jx * jy
+        wv = list(self.omega_vec)
+        wv[7] = wv[8] = w_nu
         for k in range(9):
-            m[k] = m[k] - self.omega_vec[k] * (m[k] - meq[k])
+            m[k] = m[k] - wv[k] * (m[k] - meq[k])
         out = np.empty_like(f)
         for k in range(9):
             acc = None
@@ -232,12 +250,10 @@ class CavityOracle:
     # --- a9: one iteration -------------------------------------------------------------
     def step(self, n=1):
         for _ in range(n):
+            w_nu = self.smagorinsky_omega(self.fin, self.feq, self.rho) if self.turb else None
             rho, ux, uy = self.macros(self.fin)
             feq = equ(rho, ux, uy, self.t)
-            if self.coll == "MRT":
-                fpost = self.collide(self.fin, rho, feq)
-            else:
-                fpost = self.collide(self.fin, rho, feq)
+            fpost = self.collide(self.fin, rho, feq, w_nu)
             self.stream(self.fin, fpost)
             self.wall_bc(self.fin, feq)
             self.rho = rho
@@ -247,8 +263,12 @@ class CavityOracle:
         return self
 
     def set_state(self, fin):
+        """New populations; the Smagorinsky history (previous feq, rho) is reset to the
+        equilibrium / density of the new state (same convention as lbm_set_state)."""
         self.fin = np.array(fin, dtype=self.dtype, copy=True)
         self.nsteps = 0
+        rho, ux, uy = self.macros(self.fin)
+        self.rho, self.feq = rho, equ(rho, ux, uy, self.t)
 
     def peek_macros(self):
         """rho, u that the NEXT iteration would compute from the current fin."""

@@ -17,6 +17,7 @@
  * + - * / is one IEEE operation in the order written).
  * Compiled twice: -DREAL=double -DSUF=f64 and -DREAL=float -DSUF=f32.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -64,6 +65,25 @@ static inline void equ_cell(REAL rho, REAL ux, REAL uy, const REAL t[9], REAL fe
 }
 
 /* relax[5] = omega, omegam, omega_e, omega_eps, omega_q */
+#if REAL_IS_FLOAT
+#define RSQRT(x) sqrtf(x)
+#define RABS(x) fabsf(x)
+#else
+#define RSQRT(x) sqrt(x)
+#define RABS(x) fabs(x)
+#endif
+
+/* Smagorinsky relaxation rate, MRT_GPU.py:368-387 (lines 370-373 are dead code: Cs2 is overwritten
+ * at 374).  feq_prev / rho_prev: what funRT wrote in the previous step at this cell. */
+static inline REAL smagorinsky_omega(const REAL f[9], const REAL fe_prev[9], REAL rho_prev, REAL omega) {
+    const REAL tau0 = (REAL)1.0 / omega;
+    const REAL p1 = -f[8] + (f[7] + (-f[6] + f[5]));
+    const REAL p2 = -fe_prev[8] + (fe_prev[7] + (-fe_prev[6] + fe_prev[5]));
+    const REAL q = p1 - p2;
+    const REAL tau = (REAL)0.5 * (tau0 + RSQRT(tau0 * tau0 + (((REAL)(18 * 1.4142) * (REAL)0.025) * RABS(q)) / rho_prev));
+    return (REAL)1.0 / tau;
+}
+
 static inline void collide_cell(int coll, const REAL f[9], REAL rho, const REAL feq[9], const REAL w[5],
                                 const REAL mi[9][9], REAL out[9]) {
     if (coll == COLL_SRT) { /* MRT.py:396 */
@@ -128,8 +148,11 @@ extern int lbmref_get_threads(void);
  * macroscopic fields computed in the LAST iteration (MRT.py:500-503 one-step lag).
  * Returns 0, or -1 on allocation failure / bad arguments. */
 int FN(lbmref_step)(REAL* fin, REAL* rho_out, REAL* u_out, int nx, int ny, int nsteps, int semantics,
-                    int collision, const double* relax, double uLB_d) {
-    if (nx < 4 || ny < 4 || nsteps < 0) return -1;
+                    int collision, const double* relax, double uLB_d, int turb, REAL* feq_hist) {
+    /* turb != 0: feq_hist[9][nx][ny] holds the previous step's equilibrium on entry (initially a
+     * copy of fin, MRT_GPU.py:325) and rho_out the previous step's density (initially 1); both are
+     * updated in place. */
+    if (nx < 4 || ny < 4 || nsteps < 0 || (turb && (!feq_hist || semantics != SEM_MRT_GPU))) return -1;
     const size_t n = (size_t)nx * ny;
     REAL* fpost = (REAL*)malloc(9 * n * sizeof(REAL));
     REAL* feq = (REAL*)malloc(9 * n * sizeof(REAL));
@@ -162,8 +185,14 @@ int FN(lbmref_step)(REAL* fin, REAL* rho_out, REAL* u_out, int nx, int ny, int n
                     rho = ((f[0] + f[1]) + f[3]) + (REAL)2. * ((f[2] + f[5]) + f[6]);
                     ux = uLB; uy = 0;
                 }
+                REAL wc[5] = {w[0], w[1], w[2], w[3], w[4]};
+                if (turb) {
+                    REAL fp[9];
+                    for (int k = 0; k < 9; ++k) fp[k] = F(feq_hist, k, x, y);
+                    wc[0] = smagorinsky_omega(f, fp, rho_out[(size_t)x * Y + y], w[0]);
+                }
                 equ_cell(rho, ux, uy, t, fe);
-                collide_cell(collision, f, rho, fe, w, mi, fo);
+                collide_cell(collision, f, rho, fe, wc, mi, fo);
                 for (int k = 0; k < 9; ++k) { F(feq, k, x, y) = fe[k]; F(fpost, k, x, y) = fo[k]; }
                 rho_out[(size_t)x * Y + y] = rho;
                 u_out[(size_t)x * Y + y] = ux;
@@ -232,10 +261,35 @@ int FN(lbmref_step)(REAL* fin, REAL* rho_out, REAL* u_out, int nx, int ny, int n
                 }
             }
         }
+        if (turb) memcpy(feq_hist, feq, 9 * n * sizeof(REAL));
     }
 #undef F
     free(fpost);
     free(feq);
+    return 0;
+}
+
+/* equilibrium of the macroscopic state (with wall overrides) of given populations: the
+ * Smagorinsky history after a state upload (same convention as lbm_set_state) */
+int FN(lbmref_history)(const REAL* fin, REAL* rho_out, REAL* feq_hist, int nx, int ny, double uLB_d) {
+    const size_t n = (size_t)nx * ny;
+    REAL t[9];
+    t[0] = (REAL)(4.0 / 9.0);
+    for (int k = 1; k < 5; ++k) t[k] = (REAL)(1.0 / 9.0);
+    for (int k = 5; k < 9; ++k) t[k] = (REAL)(1.0 / 36.);
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y) {
+            REAL f[9], fe[9];
+            for (int k = 0; k < 9; ++k) f[k] = fin[(size_t)k * n + (size_t)x * ny + y];
+            REAL rho = ((((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7]) + f[8]);
+            REAL ux = (((((f[1] - f[3]) + f[5]) - f[6]) - f[7]) + f[8]) / rho;
+            REAL uy = (((((f[2] - f[4]) + f[5]) + f[6]) - f[7]) - f[8]) / rho;
+            if (x == 0 || x == nx - 1 || y == ny - 1) { ux = 0; uy = 0; }
+            if (y == 0) { rho = ((f[0] + f[1]) + f[3]) + (REAL)2. * ((f[2] + f[5]) + f[6]); ux = (REAL)uLB_d; uy = 0; }
+            equ_cell(rho, ux, uy, t, fe);
+            for (int k = 0; k < 9; ++k) feq_hist[(size_t)k * n + (size_t)x * ny + y] = fe[k];
+            rho_out[(size_t)x * ny + y] = rho;
+        }
     return 0;
 }
 

@@ -30,7 +30,10 @@ def lib():
             f = getattr(_lib, "lbmref_step_" + suf)
             f.restype = ctypes.c_int
             f.argtypes = [p, p, p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                          ctypes.POINTER(ctypes.c_double), ctypes.c_double]
+                          ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_int, p]
+            h = getattr(_lib, "lbmref_history_" + suf)
+            h.restype = ctypes.c_int
+            h.argtypes = [p, p, p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
             g = getattr(_lib, "lbmref_init_" + suf)
             g.restype = ctypes.c_int
             g.argtypes = [p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
@@ -57,8 +60,9 @@ class CavityOracleC:
     """Same interface as oracle.lbm_numpy.CavityOracle, backed by lbm_ref.c."""
 
     def __init__(self, nx, ny, Re, uLB=0.08, semantics="mrt_py", collision="SRT", dtype=np.float64,
-                 omega_eps=None, omega_q=None, ny_global=None):
+                 omega_eps=None, omega_q=None, ny_global=None, turb=0):
         from .lbm_numpy import relaxation
+        self.turb = int(turb)
         self.nx, self.ny, self.uLB = nx, ny, uLB
         self.sem, self.coll = semantics, collision
         self.dtype = np.dtype(dtype)
@@ -74,6 +78,7 @@ class CavityOracleC:
         getattr(lib(), "lbmref_init_" + self._suf)(self._p(self.fin), nx, ny, uLB)
         self.rho = np.ones((nx, ny), dtype=self.dtype)
         self.u = np.zeros((2, nx, ny), dtype=self.dtype)
+        self.feq = self.fin.copy() if self.turb else None       # feq_g starts as a copy of fin (MRT_GPU.py:325)
         self.nsteps = 0
 
     def _p(self, a):
@@ -82,7 +87,8 @@ class CavityOracleC:
     def step(self, n=1):
         rc = getattr(lib(), "lbmref_step_" + self._suf)(
             self._p(self.fin), self._p(self.rho), self._p(self.u), self.nx, self.ny, int(n),
-            SEM[self.sem], COLL[self.coll], self._w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self.uLB)
+            SEM[self.sem], COLL[self.coll], self._w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self.uLB,
+            self.turb, self._p(self.feq) if self.turb else None)
         if rc != 0:
             raise RuntimeError("lbmref_step failed")
         self.nsteps += n
@@ -91,3 +97,6 @@ class CavityOracleC:
     def set_state(self, fin):
         self.fin = np.ascontiguousarray(fin, dtype=self.dtype).copy()
         self.nsteps = 0
+        if self.turb:   # Smagorinsky history := equilibrium / density of the uploaded state
+            getattr(lib(), "lbmref_history_" + self._suf)(self._p(self.fin), self._p(self.rho), self._p(self.feq),
+                                                          self.nx, self.ny, self.uLB)

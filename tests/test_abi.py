@@ -84,10 +84,10 @@ def test_create_rejects_bad_parameters():
     assert b"struct_size" in err.value
     p.struct_size = ctypes.sizeof(_lib.lbm_params)
     p.nx, p.ny, p.y0, p.ny_local = 64, 64, 0, 64
-    p.dtype, p.collision, p.semantics, p.turb = 1, 2, 1, 1
+    p.dtype, p.collision, p.semantics, p.turb = 1, 2, 0, 1     # Smagorinsky exists only with MRT_GPU semantics
     assert not L.lbm_create(ctypes.byref(p), err, len(err))
     assert b"turb" in err.value
-    p.turb, p.ny_local = 0, 1
+    p.turb, p.semantics, p.ny_local = 0, 1, 1
     assert not L.lbm_create(ctypes.byref(p), err, len(err))
     assert b"slab" in err.value
 

@@ -63,6 +63,38 @@ def test_device_layouts_give_identical_results(layout, kernel, dtype):
             same(s, o, f"mrt_py layout={layout}")
 
 
+@pytest.mark.parametrize("kernel", ["generic", "vec"])
+@pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_smagorinsky_closure_is_bit_identical_to_oracle(kernel, coll, dtype):
+    """turb = 1 (MRT_GPU.py:368-387): per-cell relaxation rate from the previous step's equilibrium."""
+    for nx, ny, layout in ((40, 24, "rows"), (260, 31, "planes")):
+        o = CavityOracleC(nx, ny, 5000.0, semantics="mrt_gpu", collision=coll, dtype=dtype, turb=1)
+        with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=1, kernel=kernel, layout=layout) as s:
+            for n in (1, 2, 57):
+                o.step(n); s.step(n)
+                same(s, o, f"turb {coll} {nx}x{ny} after {o.nsteps}")
+            # upload convention: history := equilibrium / density of the uploaded state
+            _, _, fin = s.get_fields(want_fin=True)
+            s.set_state(fin); o.set_state(fin)
+            o.step(9); s.step(9)
+            same(s, o, "turb after set_state")
+
+
+def test_smagorinsky_on_slabs():
+    nx, ny, steps = 132, 45, 30
+    with CavitySolver(nx, ny, 5000.0, RT="SRT", dtype=np.float32, turb=1) as one:
+        one.step(steps)
+        u1, r1, f1 = one.get_fields(want_fin=True)
+    slabs = [CavitySolver(nx, ny, 5000.0, RT="SRT", dtype=np.float32, turb=1, rows=r) for r in partition_rows(ny, 3)]
+    LocalSlabs(slabs).step(steps)
+    u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
+    for s in slabs:
+        s.get_fields(u=u, rho=rho, fin=fin)
+        s.close()
+    assert np.array_equal(fin, f1) and np.array_equal(u, u1) and np.array_equal(rho, r1)
+
+
 def test_config_c1_128_re100_1000_steps():
     """BASELINE.json configs[0]: 128x128, Re = 100, fp64, 1000 steps, MRT.py semantics."""
     rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
@@ -143,7 +175,7 @@ def test_argument_checks():
     with pytest.raises(ValueError):
         CavitySolver(32, 32, 100.0, RT="BGK")
     with pytest.raises(RuntimeError, match="turb"):
-        CavitySolver(32, 32, 100.0, turb=1)
+        CavitySolver(32, 32, 100.0, turb=1, semantics="mrt_py", RT="SRT")
     with pytest.raises(RuntimeError, match="nx, ny"):
         CavitySolver(2, 32, 100.0)
 
@@ -261,5 +293,8 @@ def test_front_end_drop_in(tmp_path, monkeypatch):
     assert r.regression[-1][1] > r.regression[0][1]
     o = CavityOracleC(64, 64, 100.0, semantics="mrt_gpu", collision="MRT", dtype=np.float32).step(2001)
     assert np.array_equal(r.u, o.u) and np.array_equal(r.rho, o.rho)
-    with pytest.raises(NotImplementedError):
-        run_cavity(maxIt=1, turb=1, quiet=True)
+    # the reference's default mode: SRT + Smagorinsky at Re = 10000 (MRT_GPU.py:47-49)
+    r = run_cavity(maxIt=301, Pinterval=100, xsize=96, ysize=96, SavePlot=True, SaveVTK=False, quiet=True)
+    o = CavityOracleC(96, 96, 10000.0, semantics="mrt_gpu", collision="SRT", dtype=np.float32, turb=1).step(301)
+    assert np.array_equal(r.u, o.u) and np.array_equal(r.rho, o.rho)
+    assert os.path.exists(tmp_path / "output" / "ldc_00003.png")
