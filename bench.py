@@ -103,10 +103,14 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank if local_rank < ndev else 0       # a launcher may expose one GPU per rank
+    if world > 1 and ndev < world and ndev != 1:
+        sys.exit(f"{world} ranks but {ndev} visible GPUs")
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     nx, ny_gpu, Re, dtype, RT, sem, label = CONFIGS[a.config]
     if a.scaling == "weak":
@@ -115,7 +119,7 @@ def main():
     else:
         NY = ny_gpu
         rows = partition_rows(NY, world)[rank]
-    solver = CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=local_rank,
+    solver = CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev,
                           rows=rows if world > 1 else None, kernel=a.kernel)
     if world > 1:
         attach_rccl(solver, rank, world)
