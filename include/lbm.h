@@ -137,6 +137,11 @@ int lbm_step_finish(lbm_ctx* c);
  * interior rows. */
 int lbm_comm_unique_id(void* uid_out128);
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128);
+/* Diagnostic for one-GPU machines: attaches a ONE-rank RCCL communicator and makes the slab its own
+ * neighbour on both sides (its last row arrives in its top ghost row and vice versa, i.e. periodic in y),
+ * so that lbm_step() runs the complete exchange path -- edge/interior split, second stream, events,
+ * ncclSend/ncclRecv from and into lattice memory.  Only for a slab with y0 > 0 and y0 + ny_local < ny. */
+int lbm_comm_loopback(lbm_ctx* c);
 
 /* --- measurement --------------------------------------------------------------------- */
 /* Device-to-device streaming copy of `bytes` bytes (read + write), `iters` times; returns

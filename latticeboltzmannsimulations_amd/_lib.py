@@ -74,6 +74,7 @@ SIGNATURES = {
     "lbm_step_finish": (_i, [_vp]),
     "lbm_comm_unique_id": (_i, [_vp]),
     "lbm_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "lbm_comm_loopback": (_i, [_vp]),
     "lbm_copy_bandwidth": (_i, [_vp, ctypes.c_size_t, _i, ctypes.POINTER(_d)]),
 }
 

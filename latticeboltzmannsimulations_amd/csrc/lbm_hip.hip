@@ -150,6 +150,7 @@ struct lbm_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
+    bool loopback = false;      // diagnostic: 1-rank communicator, the slab exchanges halos with itself
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     std::string err;
@@ -326,11 +327,16 @@ int enqueue_exchange(lbm_ctx* c, int which) {
     const int ny = c->geo.ny;
     NCCL_TRY(c, rccl().GroupStart());
     for (int side = 0; side < 2; ++side) {
-        const int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
+        int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
+        if (c->loopback) peer = 0;                 // the slab is its own neighbour on both sides
         if (peer < 0 || peer >= c->nranks) continue;
-        const int* out = side_planes(side);       // leaves through this side
-        const int* in = side_planes(side ^ 1);    // arrives through this side
-        const int send_row = side == LBM_SIDE_LOW ? 0 : ny - 1;
+        // planes leaving / arriving through this side.  In loopback mode both sides talk to rank 0, and RCCL
+        // pairs the i-th send to a peer with the i-th receive from it: what leaves through the OTHER side is
+        // sent here, so that the HIGH row lands in the LOW ghost row and vice versa (periodic wrap).
+        const int sside = c->loopback ? (side ^ 1) : side;
+        const int* out = side_planes(sside);
+        const int* in = side_planes(side ^ 1);
+        const int send_row = sside == LBM_SIDE_LOW ? 0 : ny - 1;
         const int recv_row = side == LBM_SIDE_LOW ? -1 : ny;
         for (int j = 0; j < 3; ++j) {
             int lo, hi;
@@ -349,7 +355,7 @@ int enqueue_exchange(lbm_ctx* c, int which) {
 int step_many(lbm_ctx* c, int nsteps) {
     const int ny = c->geo.ny;
     for (int i = 0; i < nsteps; ++i) {
-        if (c->nranks > 1) {
+        if (c->nranks > 1 || c->loopback) {
             // edges first (they need the halo that was exchanged while the previous
             // interior ran), then the interior; the next exchange starts as soon as the
             // edge rows are written and overlaps the interior kernel.
@@ -711,6 +717,23 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     NCCL_TRY(c, rccl().CommInitRank(&c->comm, nranks, id, rank));
     c->nranks = nranks;
     c->rank = rank;
+    c->halo_pending = false;
+    return LBM_OK;
+}
+
+int lbm_comm_loopback(lbm_ctx* c) {
+    if (!c) return LBM_ERR_INVALID;
+    if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
+    if (c->geo.y0 == 0 || c->geo.y0 + c->geo.ny == c->geo.NY)
+        return fail(c, LBM_ERR_INVALID, "lbm_comm_loopback needs a slab that touches neither the lid nor the bottom wall");
+    if (!rccl().ok) return fail(c, LBM_ERR_COMM, rccl().err);
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    ncclUniqueId id;
+    NCCL_TRY(c, rccl().GetUniqueId(&id));
+    NCCL_TRY(c, rccl().CommInitRank(&c->comm, 1, id, 0));
+    c->nranks = 1;
+    c->rank = 0;
+    c->loopback = true;
     c->halo_pending = false;
     return LBM_OK;
 }

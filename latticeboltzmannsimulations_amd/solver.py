@@ -166,6 +166,10 @@ class CavitySolver:
         buf = ctypes.create_string_buffer(bytes(uid_bytes), 128)
         self._check(self.lib.lbm_comm_init(self._h, int(nranks), int(rank), buf), "lbm_comm_init")
 
+    def comm_loopback(self):
+        """Diagnostic: run lbm_step's RCCL exchange path on one GPU (the slab is its own periodic neighbour)."""
+        self._check(self.lib.lbm_comm_loopback(self._h), "lbm_comm_loopback")
+
     def copy_bandwidth(self, nbytes=1 << 30, iters=10):
         g = ctypes.c_double(0.0)
         self._check(self.lib.lbm_copy_bandwidth(self._h, int(nbytes), int(iters), ctypes.byref(g)), "lbm_copy_bandwidth")
