@@ -144,7 +144,7 @@ struct lbm_ctx {
     int cur = 0;  // lat[cur] is the source of the next step
     long long nsteps = 0;
     hipStream_t s_compute = nullptr, s_comm = nullptr;
-    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     void* stage = nullptr;
     size_t stage_bytes = 0;
     ncclComm_t comm = nullptr;
@@ -323,6 +323,8 @@ int sync_all(lbm_ctx* c) {
 
 // RCCL exchange of the rows of lat[which] with both neighbours, on s_comm
 int enqueue_exchange(lbm_ctx* c, int which) {
+    static const bool skip = std::getenv("LBM_DEBUG_SKIP_EXCHANGE") != nullptr;   // timing diagnostic only: wrong results
+    if (skip) return LBM_OK;
     const ncclDataType_t dt = c->p.dtype == LBM_F32 ? ncclFloat : ncclDouble;
     const int ny = c->geo.ny;
     NCCL_TRY(c, rccl().GroupStart());
@@ -354,37 +356,43 @@ int enqueue_exchange(lbm_ctx* c, int which) {
 
 int step_many(lbm_ctx* c, int nsteps) {
     const int ny = c->geo.ny;
-    for (int i = 0; i < nsteps; ++i) {
-        if (c->nranks > 1 || c->loopback) {
-            // edges first (they need the halo that was exchanged while the previous
-            // interior ran), then the interior; the next exchange starts as soon as the
-            // edge rows are written and overlaps the interior kernel.
-            if (!c->raw[c->cur]) {
-                if (!c->halo_pending) {  // e.g. right after lbm_comm_init on a stepped lattice
-                    HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_compute));
-                    HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_edges, 0));
-                    int rc = enqueue_exchange(c, c->cur);
-                    if (rc) return rc;
-                    HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
-                }
-                HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_halo, 0));
+    if (c->nranks > 1 || c->loopback) {
+        // Two streams per slab.  s_comm (highest priority): edge rows 0 and ny-1 of step i, then the exchange of the
+        // rows just written (= the halo of step i+1).  s_compute: interior rows 1..ny-2 of step i.  Both read
+        // lattice `cur` and write the other one:
+        //   edges(i)    needs interior(i-1) [rows 1, ny-2 of cur]                    -> waits ev_int
+        //               and the halo of step i [same stream, in order]
+        //   interior(i) needs edges(i-1) [rows 0, ny-1 of cur]                       -> waits ev_edges
+        // so the tiny edge kernel and the RCCL send/recv kernel run beside the interior kernel of the same step, and
+        // the compute stream carries nothing but interior kernels back to back.
+        HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier steps)
+        for (int i = 0; i < nsteps; ++i) {
+            HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+            if (!c->raw[c->cur] && !c->halo_pending) {   // e.g. a communicator attached to a lattice already stepped
+                int rc = enqueue_exchange(c, c->cur);
+                if (rc) return rc;
             }
-            int rc = launch_step(c, 0, ny - 1, 2, c->s_compute);
+            int rc = launch_step(c, 0, ny - 1, 2, c->s_comm);
             if (rc) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_compute));
+            HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // edges of the previous step
+            HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
             rc = launch_step(c, 1, 1, ny - 2, c->s_compute);
             if (rc) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
             finish_step(c);
-            HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_edges, 0));
             rc = enqueue_exchange(c, c->cur);
             if (rc) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
             c->halo_pending = true;
-        } else {
-            int rc = launch_step(c, 0, 1, ny, c->s_compute);
-            if (rc) return rc;
-            finish_step(c);
         }
+        // a later single-stream call (export, split-step API) must see the edge rows and the halo
+        HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
+        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_halo, 0));
+        return LBM_OK;
+    }
+    for (int i = 0; i < nsteps; ++i) {
+        int rc = launch_step(c, 0, 1, ny, c->s_compute);
+        if (rc) return rc;
+        finish_step(c);
     }
     return LBM_OK;
 }
@@ -530,6 +538,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     }
     if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
     for (int i = 0; i < 2; ++i) {
@@ -552,6 +561,7 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->stage) (void)hipFree(c->stage);
     if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);
     if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    if (c->ev_int) (void)hipEventDestroy(c->ev_int);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
