@@ -56,6 +56,45 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
     }
 }
 
+// ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
+constexpr int TB_F = 4;      // cells within TB_F of a wall / slab edge are advanced by single steps
+constexpr int TB_G = 6;      // ... and the first of the two single steps covers TB_G cells
+constexpr int TB_TY = 14;    // tile rows; tile columns = 30 vectors (120 fp32 / 60 fp64 cells)
+constexpr int TB_NT = 512;   // threads per tile: phase 1 = (TB_TY + 2) rows x 32 vectors = 512 vector cells
+
+template <typename R, int COLL>
+__global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+                                                      int xe, int ye, int ntx, int ntiles) {
+    constexpr int V = 16 / (int)sizeof(R), TX = 30 * V;
+    __shared__ __align__(16) R lds[Q * (TB_TY + 2) * (TX + 2 * V)];   // 72 KiB: two tiles per CU
+    int b = blockIdx.x;
+    const int per = ntiles >> 3;
+    if (b < (per << 3)) b = (b & 7) * per + (b >> 3);   // every XCD walks its own band of tile rows
+    update_tile2<R, COLL, V, TX, TB_TY, TB_NT>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TB_TY, xe, ye);
+}
+
+// One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
+// [nx-W, nx) of the rows in between.  One thread per cell, complete wall / kept-slot logic.
+template <typename R, int COLL, int SEM>
+__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int W) {
+    const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long nrow = 2LL * W * geo.nx, ncol = 2LL * W * (geo.ny - 2 * W);
+    int x, y;
+    if (t < nrow) {
+        const int strip = (int)(t / ((long long)W * geo.nx)), o = (int)(t % ((long long)W * geo.nx));
+        x = o % geo.nx;
+        y = (strip == 0 ? 0 : geo.ny - W) + o / geo.nx;
+    } else if (t < nrow + ncol) {
+        const long long u = t - nrow, half = (long long)W * (geo.ny - 2 * W);
+        const int strip = (int)(u / half), o = (int)(u % half);
+        y = W + o / W;
+        x = (strip == 0 ? 0 : geo.nx - W) + o % W;
+    } else {
+        return;
+    }
+    update_cell<R, COLL, SEM, false>(src, dst, geo, w, 0, x, y);
+}
+
 // init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
 template <typename R>
 __global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB, int turb) {
@@ -139,7 +178,7 @@ struct lbm_ctx {
     lbm_params p{};
     int es = 0;  // element size
     Geo geo{};
-    void* lat[2] = {nullptr, nullptr};
+    void* lat[3] = {nullptr, nullptr, nullptr};   // [0], [1]: the two lattices; [2]: frame scratch of the double step
     int raw[2] = {1, 1};
     int cur = 0;  // lat[cur] is the source of the next step
     long long nsteps = 0;
@@ -153,6 +192,7 @@ struct lbm_ctx {
     bool loopback = false;      // diagnostic: 1-rank communicator, the slab exchanges halos with itself
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
+    bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
     std::string err;
 };
 
@@ -234,6 +274,23 @@ template <typename R, int COLL, int SEM, bool TURB>
 void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
     const R* src = (const R*)c->lat[c->cur];
     R* dst = (R*)c->lat[c->cur ^ 1];
+    if (row0 == -1) {   // frame of width `stride`, lattice nrows/3 -> nrows%3 (double step only, never raw)
+        const int W = stride;
+        src = (const R*)c->lat[nrows / 3];
+        dst = (R*)c->lat[nrows % 3];
+        const long long cells = 2LL * W * c->geo.nx + 2LL * W * (c->geo.ny - 2 * W);
+        hipLaunchKernelGGL((k_step_frame<R, COLL, SEM>), dim3((unsigned)((cells + BLK - 1) / BLK)), dim3(BLK), 0, s, src, dst,
+                           c->geo, relax_of<R>(c->p), W);
+        return;
+    }
+    if (row0 == -2) {   // deep interior, two steps, lat[cur] -> lat[cur^1]
+        constexpr int V = 16 / (int)sizeof(R), TX = 30 * V;
+        const int xe = c->geo.nx - TB_F, ye = c->geo.ny - TB_F;
+        const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TB_TY - 1) / TB_TY;
+        hipLaunchKernelGGL((k_step2_deep<R, COLL>), dim3(ntx * nty), dim3(TB_NT), 0, s, src, dst, c->geo, relax_of<R>(c->p),
+                           xe, ye, ntx, ntx * nty);
+        return;
+    }
     if (SEM == SEM_GPU && c->use_vec) {
         constexpr int V = 16 / (int)sizeof(R);
         const int nxb = (c->geo.nx / V + BLK - 1) / BLK;
@@ -266,6 +323,8 @@ void launch_step_r(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
     }
 }
 
+// row0 >= 0: rows row0 + i*stride, i < nrows.  row0 == -1: frame of width `stride`, lattice nrows/3 -> nrows%3.
+// row0 == -2: two steps on the deep interior, lat[cur] -> lat[cur^1].
 int launch_step(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
     if (nrows <= 0) return LBM_OK;
     if (c->p.dtype == LBM_F32) launch_step_r<float>(c, row0, stride, nrows, s);
@@ -354,45 +413,94 @@ int enqueue_exchange(lbm_ctx* c, int which) {
     return LBM_OK;
 }
 
-int step_many(lbm_ctx* c, int nsteps) {
+// Every step unit (one single step or one double step) follows one protocol on the two streams:
+//   s_comm    (highest priority): waits ev_int (interior work of the previous unit), runs the wall / slab-edge work of
+//                                 this unit and the RCCL exchanges, records ev_edges;
+//   s_compute                   : waits ev_edges of the PREVIOUS unit, runs the bulk kernel, records ev_int.
+// The small kernels and the exchange therefore run beside the bulk kernel of the same unit.
+int single_step(lbm_ctx* c, bool* comm_used) {
     const int ny = c->geo.ny;
     if (c->nranks > 1 || c->loopback) {
-        // Two streams per slab.  s_comm (highest priority): edge rows 0 and ny-1 of step i, then the exchange of the
-        // rows just written (= the halo of step i+1).  s_compute: interior rows 1..ny-2 of step i.  Both read
-        // lattice `cur` and write the other one:
-        //   edges(i)    needs interior(i-1) [rows 1, ny-2 of cur]                    -> waits ev_int
-        //               and the halo of step i [same stream, in order]
-        //   interior(i) needs edges(i-1) [rows 0, ny-1 of cur]                       -> waits ev_edges
-        // so the tiny edge kernel and the RCCL send/recv kernel run beside the interior kernel of the same step, and
-        // the compute stream carries nothing but interior kernels back to back.
-        HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier steps)
-        for (int i = 0; i < nsteps; ++i) {
-            HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
-            if (!c->raw[c->cur] && !c->halo_pending) {   // e.g. a communicator attached to a lattice already stepped
-                int rc = enqueue_exchange(c, c->cur);
-                if (rc) return rc;
-            }
-            int rc = launch_step(c, 0, ny - 1, 2, c->s_comm);
+        // edge rows 0 and ny-1 + exchange of the rows just written (the halo of the next step) | interior rows
+        HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+        if (!c->raw[c->cur] && !c->halo_pending) {   // e.g. a communicator attached to a lattice already stepped
+            int rc = enqueue_exchange(c, c->cur);
             if (rc) return rc;
-            HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // edges of the previous step
-            HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
-            rc = launch_step(c, 1, 1, ny - 2, c->s_compute);
-            if (rc) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
-            finish_step(c);
-            rc = enqueue_exchange(c, c->cur);
-            if (rc) return rc;
-            c->halo_pending = true;
         }
-        // a later single-stream call (export, split-step API) must see the edge rows and the halo
-        HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
-        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_halo, 0));
+        int rc = launch_step(c, 0, ny - 1, 2, c->s_comm);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
+        HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
+        rc = launch_step(c, 1, 1, ny - 2, c->s_compute);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+        finish_step(c);
+        rc = enqueue_exchange(c, c->cur);
+        if (rc) return rc;
+        c->halo_pending = true;
+        *comm_used = true;
         return LBM_OK;
     }
-    for (int i = 0; i < nsteps; ++i) {
-        int rc = launch_step(c, 0, 1, ny, c->s_compute);
+    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier double step
+    int rc = launch_step(c, 0, 1, ny, c->s_compute);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+    finish_step(c);
+    return LBM_OK;
+}
+
+// Two steps: lat[a] (state n) -> lat[b] (state n+2).  Bulk: k_step2_deep on cells >= TB_F away from walls and slab
+// edges.  Frame: two ordinary single steps on strips, n -> n+1 into the scratch lattice (width TB_G), n+1 -> n+2 into
+// lat[b] (width TB_F); between slabs each of the two needs its own halo, so there are two exchanges per double step.
+int double_step(lbm_ctx* c, bool* comm_used) {
+    const bool multi = c->nranks > 1 || c->loopback;
+    const int a = c->cur, b = c->cur ^ 1, t = 2;
+    HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+    int rc;
+    if (multi && !c->halo_pending) {
+        rc = enqueue_exchange(c, a);
         if (rc) return rc;
-        finish_step(c);
+    }
+    rc = launch_step(c, -1, TB_G, a * 3 + t, c->s_comm);
+    if (rc) return rc;
+    if (multi) {
+        rc = enqueue_exchange(c, t);
+        if (rc) return rc;
+    }
+    rc = launch_step(c, -1, TB_F, t * 3 + b, c->s_comm);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
+    HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
+    rc = launch_step(c, -2, 0, 1, c->s_compute);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+    c->cur ^= 1;
+    c->raw[c->cur] = 0;
+    c->nsteps += 2;
+    if (multi) {
+        rc = enqueue_exchange(c, c->cur);
+        if (rc) return rc;
+        c->halo_pending = true;
+    }
+    *comm_used = true;
+    return LBM_OK;
+}
+
+int step_many(lbm_ctx* c, int nsteps) {
+    bool comm_used = false;
+    HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier calls)
+    int left = nsteps;
+    while (left > 0) {
+        // The first step after an upload reads raw populations, and the LAST step of a call is always a single step:
+        // lbm_get_fields needs the lattice of the step before the last for the one-step lag of u / rho.
+        int rc;
+        if (c->use_tb && !c->raw[c->cur] && left >= 3) { rc = double_step(c, &comm_used); left -= 2; }
+        else { rc = single_step(c, &comm_used); left -= 1; }
+        if (rc) return rc;
+    }
+    if (comm_used) {   // later single-stream work (export, timing event, split-step API) must see the s_comm results
+        HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
+        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_halo, 0));
     }
     return LBM_OK;
 }
@@ -494,7 +602,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return bail("bad semantics");
     if (p->turb != 0 && p->turb != 1) return bail("turb must be 0 or 1");
     if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return bail("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
-    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_VEC) return bail("bad kernel variant");
+    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_TB) return bail("bad kernel variant");
     if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -525,6 +633,9 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;
         if (p->kernel == LBM_KERNEL_VEC && !can_vec) return (delete c, bail("kernel = VEC needs MRT_GPU semantics and nx % (16 / sizeof(real)) == 0"));
         c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC;
+        const bool can_tb = p->turb == 0 && p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
+        if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs turb = 0, nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
+        c->use_tb = can_tb && (p->kernel == LBM_KERNEL_AUTO || p->kernel == LBM_KERNEL_TB);
         const char* nt = std::getenv("LBM_NT");
         c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
     }
@@ -541,7 +652,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < (c->use_tb ? 3 : 2); ++i) {
         if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
         // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
         if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
@@ -556,7 +667,7 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->s_compute) (void)hipStreamSynchronize(c->s_compute);
     if (c->s_comm) (void)hipStreamSynchronize(c->s_comm);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
         if (c->lat[i]) (void)hipFree(c->lat[i]);
     if (c->stage) (void)hipFree(c->stage);
     if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);

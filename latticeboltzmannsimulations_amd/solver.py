@@ -11,7 +11,7 @@ from . import _lib as L
 _DT = {np.dtype(np.float32): L.LBM_F32, np.dtype(np.float64): L.LBM_F64}
 _COLL = {"SRT": L.LBM_SRT, "TRT": L.LBM_TRT, "MRT": L.LBM_MRT}
 _SEM = {"mrt_py": L.LBM_SEM_MRT_PY, "mrt_gpu": L.LBM_SEM_MRT_GPU}
-_KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC}
+_KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC, "tb": L.LBM_KERNEL_TB}
 _LAYOUT = {"auto": L.LBM_LAYOUT_AUTO, "planes": L.LBM_LAYOUT_PLANES, "rows": L.LBM_LAYOUT_ROWS}
 
 
@@ -36,7 +36,8 @@ class CavitySolver:
                    or 'mrt_py' (the CPU script's windows and wall rules, MRT.py:404-453)
     dtype        : float32 (what MRT_GPU.py stores, MRT_GPU.py:207) or float64 (what MRT.py computes in)
     rows         : (y0, ny_local) when this object holds only a slab
-    kernel       : 'auto' | 'generic' (one thread per cell) | 'vec' (16 B per access, MRT_GPU.py semantics)
+    kernel       : 'auto' | 'generic' (one thread per cell) | 'vec' (16 B per access, MRT_GPU.py semantics) |
+                   'tb' (two steps per launch on the interior through LDS; what 'auto' picks when it applies)
     layout       : device arrays 'planes' [k][y][x], 'rows' [y][k][x], 'auto' (= rows)
     """
 

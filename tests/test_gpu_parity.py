@@ -95,6 +95,33 @@ def test_smagorinsky_on_slabs():
     assert np.array_equal(fin, f1) and np.array_equal(u, u1) and np.array_equal(rho, r1)
 
 
+@pytest.mark.parametrize("sem", ["mrt_gpu", "mrt_py"])
+@pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_steps_per_launch_is_bit_identical_to_oracle(sem, coll, dtype):
+    """kernel='tb': temporal blocking through LDS on the interior + single steps on the frame.  Sizes with partial
+    tiles in x and y, one tile only, and many tiles; step counts that mix single and double steps."""
+    for nx, ny, layout in ((260, 75, "rows"), (64, 33, "planes"), (132, 131, "rows")):
+        o = CavityOracleC(nx, ny, 400.0, semantics=sem, collision=coll, dtype=dtype)
+        with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=dtype, kernel="tb", layout=layout) as s:
+            for n in (1, 2, 3, 4, 5, 64):
+                o.step(n); s.step(n)
+                same(s, o, f"tb {sem} {coll} {nx}x{ny} after {o.nsteps} steps")
+            _, _, fin = s.get_fields(want_fin=True)
+            s.set_state(fin); o.set_state(fin)
+            o.step(11); s.step(11)
+            same(s, o, "tb after set_state")
+
+
+def test_two_steps_per_launch_needs_its_preconditions():
+    with pytest.raises(RuntimeError, match="kernel = TB"):
+        CavitySolver(64, 64, 100.0, kernel="tb", turb=1)
+    with pytest.raises(RuntimeError, match="kernel = TB"):
+        CavitySolver(24, 64, 100.0, kernel="tb")
+    with pytest.raises(RuntimeError, match="kernel = TB"):
+        CavitySolver(66, 64, 100.0, kernel="tb", dtype=np.float32)
+
+
 def test_config_c1_128_re100_1000_steps():
     """BASELINE.json configs[0]: 128x128, Re = 100, fp64, 1000 steps, MRT.py semantics."""
     rec = json.load(open(os.path.join(GOLDEN, "survey_appendix_c.json")))
@@ -241,19 +268,20 @@ def test_fp32_tracks_fp64():
 
 def test_full_size_properties_4096_fp32():
     """BASELINE.json configs[2] size (4096^2, fp32, MRT): properties that need no CPU oracle run --
-    4 slabs == 1 slab bit for bit, generic kernel == default kernel, mass drift bounded, finite."""
-    n, steps = 4096, 6
+    4 slabs == 1 slab bit for bit, one-step kernels == default (two-steps-per-launch) kernel, mass drift bounded."""
+    n, steps = 4096, 8
     with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as one:
         one.step(steps)
         u1, r1, f1 = one.get_fields(want_fin=True)
     assert np.isfinite(f1).all()
     mass0 = float(n) * n                                   # rho = 1 everywhere at t = 0
     assert abs(f1.sum(dtype=np.float64) - mass0) / mass0 < 1e-4
-    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, kernel="generic") as g:
-        g.step(steps)
-        ug, rg, fg = g.get_fields(want_fin=True)
-    assert np.array_equal(fg, f1) and np.array_equal(ug, u1) and np.array_equal(rg, r1)
-    del ug, rg, fg
+    for kern in ("generic", "vec"):
+        with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, kernel=kern) as g:
+            g.step(steps)
+            ug, rg, fg = g.get_fields(want_fin=True)
+        assert np.array_equal(fg, f1) and np.array_equal(ug, u1) and np.array_equal(rg, r1), kern
+        del ug, rg, fg
     slabs = [CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, rows=r) for r in partition_rows(n, 4)]
     LocalSlabs(slabs).step(steps)
     u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
