@@ -45,15 +45,21 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
     const int per = nblocks >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
     const int y = row0 + (b / nxb) * row_stride;
-    const int x0 = ((b % nxb) * BLK + threadIdx.x) * V;
-    if (x0 >= geo.nx) return;
     const int gy = geo.y0 + y;
     if (gy == 0 || gy == geo.NY - 1) {
+        // lid / bottom-wall row: one cell per thread and pass (consecutive threads -> consecutive cells), so that a
+        // narrow lattice needs ONE pass instead of V dependent ones -- on small lattices this row is the critical path
+        const int xb0 = (b % nxb) * BLK * V;
 #pragma unroll 1
-        for (int c = 0; c < V; ++c) update_cell<R, COLL, SEM_GPU, TURB>(src, dst, geo, w, raw, x0 + c, y);
-    } else {
-        update_vec<R, COLL, V, NT, TURB>(src, dst, geo, w, raw, x0, y);
+        for (int j = 0; j < V; ++j) {
+            const int x = xb0 + j * BLK + threadIdx.x;
+            if (x < geo.nx) update_cell<R, COLL, SEM_GPU, TURB>(src, dst, geo, w, raw, x, y);
+        }
+        return;
     }
+    const int x0 = ((b % nxb) * BLK + threadIdx.x) * V;
+    if (x0 >= geo.nx) return;
+    update_vec<R, COLL, V, NT, TURB>(src, dst, geo, w, raw, x0, y);
 }
 
 // ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
@@ -441,10 +447,10 @@ int single_step(lbm_ctx* c, bool* comm_used) {
         *comm_used = true;
         return LBM_OK;
     }
-    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier double step
+    if (c->use_tb) HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier double step
     int rc = launch_step(c, 0, 1, ny, c->s_compute);
     if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+    if (c->use_tb) HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
     finish_step(c);
     return LBM_OK;
 }
@@ -488,7 +494,8 @@ int double_step(lbm_ctx* c, bool* comm_used) {
 
 int step_many(lbm_ctx* c, int nsteps) {
     bool comm_used = false;
-    HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier calls)
+    if (c->use_tb || c->nranks > 1 || c->loopback)   // (a lone slab stepping one step per launch uses one stream, no events)
+        HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier calls)
     int left = nsteps;
     while (left > 0) {
         // The first step after an upload reads raw populations, and the LAST step of a call is always a single step:
@@ -635,7 +642,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC;
         const bool can_tb = p->turb == 0 && p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
         if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs turb = 0, nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
-        c->use_tb = can_tb && (p->kernel == LBM_KERNEL_AUTO || p->kernel == LBM_KERNEL_TB);
+        // measured crossover (gpurun_out/perf4.log): below ~768^2 cells a step is launch-bound and the three launches of
+        // a double step do not pay
+        const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;
+        c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
         const char* nt = std::getenv("LBM_NT");
         c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
     }
