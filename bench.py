@@ -65,8 +65,8 @@ def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=12.0):
     threads = max(1, min(lbm_ref.max_threads(), host_cores()))
     lbm_ref.set_threads(threads)
     o = lbm_ref.CavityOracleC(nx, ny, Re, semantics=semantics, collision=RT, dtype=np.dtype(dtype))
-    o.step(1)                                   # first touch
-    t = time.perf_counter(); o.step(1); one = time.perf_counter() - t
+    o.step(2)                                   # first touch, thread pool warm
+    t = time.perf_counter(); o.step(2); one = (time.perf_counter() - t) / 2
     n = int(max(2, min(200, budget_s / max(one, 1e-6))))
     t = time.perf_counter(); o.step(n); dt = time.perf_counter() - t
     lbm_ref.set_threads(1)
@@ -142,12 +142,15 @@ def main():
         dt, ev_ms = float(t[0]), float(t[1])
 
     cells_total = nx * NY
-    cells_launch = nx * rows[1]
+    cells_rank = nx * rows[1]
     es = np.dtype(dtype).itemsize
     mlups = cells_total * a.steps / dt / 1e6
-    alg_bytes_launch = cells_launch * 2 * 9 * es                 # read 9 + write 9 populations per cell
-    kern_ms = ev_ms / a.steps
-    achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
+    # algorithmic bytes per lattice update = read 9 + write 9 populations = 18 * sizeof(real).
+    # The dominant kernel (k_step2_deep, two time steps per launch) performs 2 updates of every interior cell per launch;
+    # the K timed steps are (K-2)/2 such launches + 2 single-step launches, bracketed by HIP events on the compute stream.
+    alg_bytes_step = cells_rank * 2 * 9 * es
+    step_ms = ev_ms / a.steps
+    achieved = alg_bytes_step / (step_ms * 1e-3) / 1e9
 
     out = None
     if rank == 0:
@@ -155,7 +158,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(f"{a.config}:{world}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tp)).get(f"{a.config}:{world}:{a.kernel}", {}).get("hbm_bytes_per_step")
             except Exception:
                 traffic = None
         other = {}
@@ -174,7 +177,10 @@ def main():
                        "halo": "rccl send/recv inside lbm_step, overlapped" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": alg_bytes_launch},
+                         "event_ms_per_step": round(step_ms, 5), "algorithmic_bytes_per_step": alg_bytes_step,
+                         "note": "achieved = algorithmic bytes (18 words per cell update) / HIP-event time; with two time steps "
+                                 "fused per launch through LDS the HBM bytes actually moved (traffic, per step) are below the "
+                                 "algorithmic bytes, so achieved can exceed the physical peak"},
         }
         if other:
             out["other"] = other

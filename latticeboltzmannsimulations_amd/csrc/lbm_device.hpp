@@ -449,12 +449,20 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
         T in[Q], outv[Q];
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
-            const R* p = lds + ((k * PH + (r + 1 + cyk(k))) * PW + (V + vc * V - cxk(k)));
+            // one aligned 16-byte LDS read of the thread's own columns + ONE scalar for the x -+ 1 neighbour
+            // (V scalar reads at a stride of V words are a V-way bank conflict)
+            const R* p = lds + ((k * PH + (r + 1 + cyk(k))) * PW + (V + vc * V));
+            const T own = *reinterpret_cast<const T*>(p);
             if (cxk(k) == 0) {
-                in[k] = *reinterpret_cast<const T*>(p);
+                in[k] = own;
+            } else if (cxk(k) > 0) {
+                in[k][0] = p[-1];
+#pragma unroll
+                for (int c = 1; c < V; ++c) in[k][c] = own[c - 1];
             } else {
 #pragma unroll
-                for (int c = 0; c < V; ++c) in[k][c] = p[c];
+                for (int c = 0; c < V - 1; ++c) in[k][c] = own[c + 1];
+                in[k][V - 1] = p[V];
             }
         }
         collide_vec<R, COLL, V>(in, w, outv);
