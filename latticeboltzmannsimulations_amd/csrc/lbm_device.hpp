@@ -401,16 +401,20 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
 // hold garbage -- harmless.  Per-cell arithmetic is the same operation sequence as update_cell,
 // so the result is bit-identical to two single steps.
 // ------------------------------------------------------------------------------------------
-template <typename R, int COLL, int V>
-__device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in)[Q], const Relax<R>& w,
-                                            typename VecT<R, V>::type (&outv)[Q]) {
+template <typename R, int COLL, int V, bool TURB>
+__device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in)[Q], const Relax<R>& w0,
+                                            typename VecT<R, V>::type (&outv)[Q],
+                                            typename VecT<R, V>::type& hq, typename VecT<R, V>::type& hr) {
+    // hq, hr: Smagorinsky history of the cells (in: previous step, out: this step); untouched unless TURB
 #pragma unroll
     for (int c = 0; c < V; ++c) {
         R g[Q], out[Q], fe[Q];
 #pragma unroll
         for (int k = 0; k < Q; ++k) g[k] = in[k][c];
+        Relax<R> w = w0;
+        if (TURB) w.w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
         const R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
-        if (COLL != C_MRT) {
+        if (COLL != C_MRT || TURB) {
             const R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
             const R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
             equ<R>(rho, ux, uy, fe);
@@ -418,26 +422,35 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
         collide<R, COLL>(g, rho, fe, w, out);
 #pragma unroll
         for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
+        if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
     }
 }
 
-template <typename R, int COLL, int V, int TX, int TY, int NT>
+template <typename R, int COLL, int V, int TX, int TY, int NT, bool TURB>
 __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
                                              const Relax<R>& w, R* __restrict__ lds, int tx0, int ty0, int xe, int ye) {
     typedef typename VecT<R, V>::type T;
     constexpr int PW = TX + 2 * V, PH = TY + 2, PVC = PW / V, TVC = TX / V;
-    // phase 1: rows ty0-1 .. ty0+TY, columns tx0-V .. tx0+TX+V-1  ->  lds[Q][PH][PW]
+    // phase 1: rows ty0-1 .. ty0+TY, columns tx0-V .. tx0+TX+V-1  ->  lds[Q (+2)][PH][PW]
     for (int i = threadIdx.x; i < PH * PVC; i += NT) {
         const int r = i / PVC, vc = i - r * PVC;
         const int x0 = tx0 - V + vc * V, y = ty0 - 1 + r;
         if (x0 < geo.nx && y < geo.ny) {
-            T in[Q], outv[Q];
+            T in[Q], outv[Q], hq, hr;
 #pragma unroll
             for (int k = 0; k < Q; ++k)
                 in[k] = vload<R, V, false>(src + k * geo.plane + geo.at(x0 - cxk(k), y + cyk(k)), cxk(k) == 0);
-            collide_vec<R, COLL, V>(in, w, outv);
+            if (TURB) {
+                hq = vload<R, V, false>(src + K_QEQ * geo.plane + geo.at(x0, y), true);
+                hr = vload<R, V, false>(src + K_RHO * geo.plane + geo.at(x0, y), true);
+            }
+            collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);
 #pragma unroll
             for (int k = 0; k < Q; ++k) *reinterpret_cast<T*>(lds + ((k * PH + r) * PW + vc * V)) = outv[k];
+            if (TURB) {
+                *reinterpret_cast<T*>(lds + ((K_QEQ * PH + r) * PW + vc * V)) = hq;
+                *reinterpret_cast<T*>(lds + ((K_RHO * PH + r) * PW + vc * V)) = hr;
+            }
         }
     }
     __syncthreads();
@@ -446,7 +459,7 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
         const int r = i / TVC, vc = i - r * TVC;
         const int x0 = tx0 + vc * V, y = ty0 + r;
         if (x0 >= xe || y >= ye) continue;
-        T in[Q], outv[Q];
+        T in[Q], outv[Q], hq, hr;
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
             // one aligned 16-byte LDS read of the thread's own columns + ONE scalar for the x -+ 1 neighbour
@@ -465,10 +478,18 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
                 in[k][V - 1] = p[V];
             }
         }
-        collide_vec<R, COLL, V>(in, w, outv);
+        if (TURB) {
+            hq = *reinterpret_cast<const T*>(lds + ((K_QEQ * PH + (r + 1)) * PW + (V + vc * V)));
+            hr = *reinterpret_cast<const T*>(lds + ((K_RHO * PH + (r + 1)) * PW + (V + vc * V)));
+        }
+        collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);
         const long long me = geo.at(x0, y);
 #pragma unroll
         for (int k = 0; k < Q; ++k) vstore<R, V, false>(dst + k * geo.plane + me, outv[k]);
+        if (TURB) {
+            vstore<R, V, false>(dst + K_QEQ * geo.plane + me, hq);
+            vstore<R, V, false>(dst + K_RHO * geo.plane + me, hr);
+        }
     }
 }
 

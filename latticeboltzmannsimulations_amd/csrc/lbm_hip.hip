@@ -65,23 +65,25 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
 // ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
 constexpr int TB_F = 4;      // cells within TB_F of a wall / slab edge are advanced by single steps
 constexpr int TB_G = 6;      // ... and the first of the two single steps covers TB_G cells
-constexpr int TB_TY = 14;    // tile rows; tile columns = 30 vectors (120 fp32 / 60 fp64 cells)
-constexpr int TB_NT = 512;   // threads per tile: phase 1 = (TB_TY + 2) rows x 32 vectors = 512 vector cells
+constexpr int TB_NT = 512;   // threads per tile: phase 1 = (TY + 2) rows x 32 vectors (= 512 vector cells for TY = 14)
+// tile: 30 vectors wide (120 fp32 / 60 fp64 cells), 14 rows -- 12 with the two Smagorinsky history planes, so that two
+// tiles still fit the 160 KiB of LDS of a CU (9 x 16 x 128 x 4 B = 72 KiB; 11 x 14 x 128 x 4 B = 77 KiB)
+template <bool TURB> constexpr int tb_ty() { return TURB ? 12 : 14; }
 
-template <typename R, int COLL>
+template <typename R, int COLL, bool TURB>
 __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                       int xe, int ye, int ntx, int ntiles) {
-    constexpr int V = 16 / (int)sizeof(R), TX = 30 * V;
-    __shared__ __align__(16) R lds[Q * (TB_TY + 2) * (TX + 2 * V)];   // 72 KiB: two tiles per CU
+    constexpr int V = 16 / (int)sizeof(R), TX = 30 * V, TY = tb_ty<TURB>();
+    __shared__ __align__(16) R lds[(TURB ? Q + 2 : Q) * (TY + 2) * (TX + 2 * V)];
     int b = blockIdx.x;
     const int per = ntiles >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);   // every XCD walks its own band of tile rows
-    update_tile2<R, COLL, V, TX, TB_TY, TB_NT>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TB_TY, xe, ye);
+    update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
 // One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
 // [nx-W, nx) of the rows in between.  One thread per cell, complete wall / kept-slot logic.
-template <typename R, int COLL, int SEM>
+template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int W) {
     const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long nrow = 2LL * W * geo.nx, ncol = 2LL * W * (geo.ny - 2 * W);
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R
     } else {
         return;
     }
-    update_cell<R, COLL, SEM, false>(src, dst, geo, w, 0, x, y);
+    update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, 0, x, y);
 }
 
 // init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
@@ -285,15 +287,15 @@ void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
         src = (const R*)c->lat[nrows / 3];
         dst = (R*)c->lat[nrows % 3];
         const long long cells = 2LL * W * c->geo.nx + 2LL * W * (c->geo.ny - 2 * W);
-        hipLaunchKernelGGL((k_step_frame<R, COLL, SEM>), dim3((unsigned)((cells + BLK - 1) / BLK)), dim3(BLK), 0, s, src, dst,
+        hipLaunchKernelGGL((k_step_frame<R, COLL, SEM, TURB>), dim3((unsigned)((cells + BLK - 1) / BLK)), dim3(BLK), 0, s, src, dst,
                            c->geo, relax_of<R>(c->p), W);
         return;
     }
     if (row0 == -2) {   // deep interior, two steps, lat[cur] -> lat[cur^1]
-        constexpr int V = 16 / (int)sizeof(R), TX = 30 * V;
+        constexpr int V = 16 / (int)sizeof(R), TX = 30 * V, TY = tb_ty<TURB>();
         const int xe = c->geo.nx - TB_F, ye = c->geo.ny - TB_F;
-        const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TB_TY - 1) / TB_TY;
-        hipLaunchKernelGGL((k_step2_deep<R, COLL>), dim3(ntx * nty), dim3(TB_NT), 0, s, src, dst, c->geo, relax_of<R>(c->p),
+        const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
+        hipLaunchKernelGGL((k_step2_deep<R, COLL, TURB>), dim3(ntx * nty), dim3(TB_NT), 0, s, src, dst, c->geo, relax_of<R>(c->p),
                            xe, ye, ntx, ntx * nty);
         return;
     }
@@ -640,8 +642,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;
         if (p->kernel == LBM_KERNEL_VEC && !can_vec) return (delete c, bail("kernel = VEC needs MRT_GPU semantics and nx % (16 / sizeof(real)) == 0"));
         c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC;
-        const bool can_tb = p->turb == 0 && p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
-        if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs turb = 0, nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
+        const bool can_tb = p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
+        if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
         // measured crossover (gpurun_out/perf4.log): below ~768^2 cells a step is launch-bound and the three launches of
         // a double step do not pay
         const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;

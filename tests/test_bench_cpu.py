@@ -1,0 +1,34 @@
+"""CPU checks of bench.py's host-side pieces (no GPU): configs table, CPU-share detection, the cpu_baseline leg."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_configs_follow_baseline_json():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "4096" in base["configs"][2] and "fp32" in base["configs"][2]
+    nx, ny, Re, dtype, RT, sem, _ = bench.CONFIGS["c3"]
+    assert (nx, ny, Re, dtype, RT, sem) == (4096, 4096, 1000.0, "float32", "MRT", "mrt_gpu")
+    assert bench.CONFIGS["c2"][:4] == (1024, 1024, 1000.0, "float64")
+    assert bench.CONFIGS["c5"][:2] == (16384, 2048)      # 16384^2 / 8 GPUs
+
+
+def test_host_cores_is_positive_and_bounded():
+    n = bench.host_cores()
+    assert 1 <= n <= 32
+
+
+def test_cpu_baseline_leg_runs_on_a_small_sample():
+    r = bench.cpu_baseline(128, 128, 1000.0, "float32", "MRT", "mrt_gpu", budget_s=0.3)
+    assert r["kind"] == "port" and r["unit"] == "MLUPS" and r["value"] > 0.1 and r["cores"] >= 1
+
+
+def test_wrong_world_size_is_refused():
+    env = dict(os.environ, WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
+    assert p.returncode != 0 and "torch.distributed.run" in (p.stderr + p.stdout)
