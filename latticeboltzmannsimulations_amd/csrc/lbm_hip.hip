@@ -65,15 +65,18 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
 // ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
 constexpr int TB_F = 4;      // cells within TB_F of a wall / slab edge are advanced by single steps
 constexpr int TB_G = 6;      // ... and the first of the two single steps covers TB_G cells
-constexpr int TB_NT = 512;   // threads per tile: phase 1 = (TY + 2) rows x 32 vectors (= 512 vector cells for TY = 14)
-// tile: 30 vectors wide (120 fp32 / 60 fp64 cells), 14 rows -- 12 with the two Smagorinsky history planes, so that two
-// tiles still fit the 160 KiB of LDS of a CU (9 x 16 x 128 x 4 B = 72 KiB; 11 x 14 x 128 x 4 B = 77 KiB)
-template <bool TURB> constexpr int tb_ty() { return TURB ? 12 : 14; }
+constexpr int TB_NT = 512;   // threads per tile
+// Tile shape (measured sweep, gpurun_out/tb2.log, tb3.log): wide and short wins -- 62 vectors (248 fp32 / 124 fp64 cells)
+// x 6 rows: phase 1 is 8 rows x 64 vectors = exactly one vector cell per thread and one wave per 1-KiB row segment
+// (9 x 8 x 256 x 4 B = 72 KiB of LDS: two tiles per CU).  The row re-reads of the short tile are served by L2.
+// With the two Smagorinsky history planes: 30 vectors x 12 rows (11 x 14 x 128 x 4 B = 77 KiB).
+template <bool TURB> constexpr int tb_ty() { return TURB ? 12 : 6; }
+template <bool TURB> constexpr int tb_txv() { return TURB ? 30 : 62; }
 
 template <typename R, int COLL, bool TURB>
 __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                       int xe, int ye, int ntx, int ntiles) {
-    constexpr int V = 16 / (int)sizeof(R), TX = 30 * V, TY = tb_ty<TURB>();
+    constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<TURB>() * V, TY = tb_ty<TURB>();
     __shared__ __align__(16) R lds[(TURB ? Q + 2 : Q) * (TY + 2) * (TX + 2 * V)];
     int b = blockIdx.x;
     const int per = ntiles >> 3;
@@ -292,7 +295,7 @@ void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
         return;
     }
     if (row0 == -2) {   // deep interior, two steps, lat[cur] -> lat[cur^1]
-        constexpr int V = 16 / (int)sizeof(R), TX = 30 * V, TY = tb_ty<TURB>();
+        constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<TURB>() * V, TY = tb_ty<TURB>();
         const int xe = c->geo.nx - TB_F, ye = c->geo.ny - TB_F;
         const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
         hipLaunchKernelGGL((k_step2_deep<R, COLL, TURB>), dim3(ntx * nty), dim3(TB_NT), 0, s, src, dst, c->geo, relax_of<R>(c->p),
