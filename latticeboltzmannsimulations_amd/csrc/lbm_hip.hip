@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/lbm.h"
@@ -280,66 +281,85 @@ Relax<R> relax_of(const lbm_params& p) {
 
 dim3 grid_rows(const lbm_ctx* c, int nrows) { return dim3((c->geo.nx + BLK - 1) / BLK, nrows, 1); }
 
-// launch the fused step on rows row0 + i*stride, i in [0, nrows)
-template <typename R, int COLL, int SEM, bool TURB>
-void launch_step_t(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
-    const R* src = (const R*)c->lat[c->cur];
-    R* dst = (R*)c->lat[c->cur ^ 1];
-    if (row0 == -1) {   // frame of width `stride`, lattice nrows/3 -> nrows%3 (double step only, never raw)
-        const int W = stride;
-        src = (const R*)c->lat[nrows / 3];
-        dst = (R*)c->lat[nrows % 3];
+// Run-time parameters -> compile-time kernel variant (real type, collision operator, semantics, Smagorinsky).
+template <typename R_, int COLL_, int SEM_, bool TURB_>
+struct Variant {
+    using R = R_;
+    static constexpr int COLL = COLL_, SEM = SEM_;
+    static constexpr bool TURB = TURB_;
+};
+
+template <typename F>
+void dispatch(const lbm_params& p, F&& f) {
+    auto by_sem = [&](auto real, auto coll) {
+        using R = decltype(real);
+        constexpr int C = decltype(coll)::value;
+        if (p.semantics == LBM_SEM_MRT_PY) f(Variant<R, C, SEM_PY, false>{});
+        else if (p.turb) f(Variant<R, C, SEM_GPU, true>{});
+        else f(Variant<R, C, SEM_GPU, false>{});
+    };
+    auto by_coll = [&](auto real) {
+        switch (p.collision) {
+            case LBM_SRT: by_sem(real, std::integral_constant<int, C_SRT>{}); break;
+            case LBM_TRT: by_sem(real, std::integral_constant<int, C_TRT>{}); break;
+            default: by_sem(real, std::integral_constant<int, C_MRT>{}); break;
+        }
+    };
+    if (p.dtype == LBM_F32) by_coll(float{});
+    else by_coll(double{});
+}
+
+// One single step, lat[cur] -> lat[cur^1], on local rows row0 + i*stride, i in [0, nrows).
+int launch_rows(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
+    if (nrows <= 0) return LBM_OK;
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
+        const R* src = (const R*)c->lat[c->cur];
+        R* dst = (R*)c->lat[c->cur ^ 1];
+        const int raw = c->raw[c->cur];
+        if (VT::SEM == SEM_GPU && c->use_vec) {
+            constexpr int V = 16 / (int)sizeof(R);
+            const int nxb = (c->geo.nx / V + BLK - 1) / BLK, nblocks = nxb * nrows;
+            if (c->use_nt)
+                hipLaunchKernelGGL((k_step_vec<R, VT::COLL, V, true, VT::TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
+                                   relax_of<R>(c->p), raw, row0, stride, nxb, nblocks);
+            else
+                hipLaunchKernelGGL((k_step_vec<R, VT::COLL, V, false, VT::TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
+                                   relax_of<R>(c->p), raw, row0, stride, nxb, nblocks);
+        } else {
+            hipLaunchKernelGGL((k_step_generic<R, VT::COLL, VT::SEM, VT::TURB>), grid_rows(c, nrows), dim3(BLK), 0, s, src, dst,
+                               c->geo, relax_of<R>(c->p), raw, row0, stride);
+        }
+    });
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+// One single step on the frame of width W, lat[from] -> lat[to] (part of a double step; never a raw lattice).
+int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s) {
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
         const long long cells = 2LL * W * c->geo.nx + 2LL * W * (c->geo.ny - 2 * W);
-        hipLaunchKernelGGL((k_step_frame<R, COLL, SEM, TURB>), dim3((unsigned)((cells + BLK - 1) / BLK)), dim3(BLK), 0, s, src, dst,
-                           c->geo, relax_of<R>(c->p), W);
-        return;
-    }
-    if (row0 == -2) {   // deep interior, two steps, lat[cur] -> lat[cur^1]
-        constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<TURB>() * V, TY = tb_ty<TURB>();
+        hipLaunchKernelGGL((k_step_frame<R, VT::COLL, VT::SEM, VT::TURB>), dim3((unsigned)((cells + BLK - 1) / BLK)), dim3(BLK), 0, s,
+                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), W);
+    });
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+// Two steps on the deep interior, lat[from] -> lat[to].
+int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
+        constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<VT::TURB>() * V, TY = tb_ty<VT::TURB>();
         const int xe = c->geo.nx - TB_F, ye = c->geo.ny - TB_F;
         const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
-        hipLaunchKernelGGL((k_step2_deep<R, COLL, TURB>), dim3(ntx * nty), dim3(TB_NT), 0, s, src, dst, c->geo, relax_of<R>(c->p),
-                           xe, ye, ntx, ntx * nty);
-        return;
-    }
-    if (SEM == SEM_GPU && c->use_vec) {
-        constexpr int V = 16 / (int)sizeof(R);
-        const int nxb = (c->geo.nx / V + BLK - 1) / BLK;
-        const int nblocks = nxb * nrows;
-        if (c->use_nt)
-            hipLaunchKernelGGL((k_step_vec<R, COLL, V, true, TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
-                               relax_of<R>(c->p), c->raw[c->cur], row0, stride, nxb, nblocks);
-        else
-            hipLaunchKernelGGL((k_step_vec<R, COLL, V, false, TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
-                               relax_of<R>(c->p), c->raw[c->cur], row0, stride, nxb, nblocks);
-        return;
-    }
-    hipLaunchKernelGGL((k_step_generic<R, COLL, SEM, TURB>), grid_rows(c, nrows), dim3(BLK), 0, s, src, dst, c->geo,
-                       relax_of<R>(c->p), c->raw[c->cur], row0, stride);
-}
-
-template <typename R, int COLL>
-void launch_step_c(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
-    if (c->p.semantics == LBM_SEM_MRT_PY) launch_step_t<R, COLL, SEM_PY, false>(c, row0, stride, nrows, s);
-    else if (c->p.turb) launch_step_t<R, COLL, SEM_GPU, true>(c, row0, stride, nrows, s);
-    else launch_step_t<R, COLL, SEM_GPU, false>(c, row0, stride, nrows, s);
-}
-
-template <typename R>
-void launch_step_r(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
-    switch (c->p.collision) {
-        case LBM_SRT: launch_step_c<R, C_SRT>(c, row0, stride, nrows, s); break;
-        case LBM_TRT: launch_step_c<R, C_TRT>(c, row0, stride, nrows, s); break;
-        default: launch_step_c<R, C_MRT>(c, row0, stride, nrows, s); break;
-    }
-}
-
-// row0 >= 0: rows row0 + i*stride, i < nrows.  row0 == -1: frame of width `stride`, lattice nrows/3 -> nrows%3.
-// row0 == -2: two steps on the deep interior, lat[cur] -> lat[cur^1].
-int launch_step(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
-    if (nrows <= 0) return LBM_OK;
-    if (c->p.dtype == LBM_F32) launch_step_r<float>(c, row0, stride, nrows, s);
-    else launch_step_r<double>(c, row0, stride, nrows, s);
+        hipLaunchKernelGGL((k_step2_deep<R, VT::COLL, VT::TURB>), dim3(ntx * nty), dim3(TB_NT), 0, s, (const R*)c->lat[from],
+                           (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
+    });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
 }
@@ -438,11 +458,11 @@ int single_step(lbm_ctx* c, bool* comm_used) {
             int rc = enqueue_exchange(c, c->cur);
             if (rc) return rc;
         }
-        int rc = launch_step(c, 0, ny - 1, 2, c->s_comm);
+        int rc = launch_rows(c, 0, ny - 1, 2, c->s_comm);
         if (rc) return rc;
         HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
         HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
-        rc = launch_step(c, 1, 1, ny - 2, c->s_compute);
+        rc = launch_rows(c, 1, 1, ny - 2, c->s_compute);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
         finish_step(c);
@@ -453,7 +473,7 @@ int single_step(lbm_ctx* c, bool* comm_used) {
         return LBM_OK;
     }
     if (c->use_tb) HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier double step
-    int rc = launch_step(c, 0, 1, ny, c->s_compute);
+    int rc = launch_rows(c, 0, 1, ny, c->s_compute);
     if (rc) return rc;
     if (c->use_tb) HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
     finish_step(c);
@@ -472,17 +492,17 @@ int double_step(lbm_ctx* c, bool* comm_used) {
         rc = enqueue_exchange(c, a);
         if (rc) return rc;
     }
-    rc = launch_step(c, -1, TB_G, a * 3 + t, c->s_comm);
+    rc = launch_frame(c, a, t, TB_G, c->s_comm);
     if (rc) return rc;
     if (multi) {
         rc = enqueue_exchange(c, t);
         if (rc) return rc;
     }
-    rc = launch_step(c, -1, TB_F, t * 3 + b, c->s_comm);
+    rc = launch_frame(c, t, b, TB_F, c->s_comm);
     if (rc) return rc;
     HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
     HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
-    rc = launch_step(c, -2, 0, 1, c->s_compute);
+    rc = launch_deep(c, a, b, c->s_compute);
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
     c->cur ^= 1;
@@ -818,13 +838,13 @@ int lbm_halo_import(lbm_ctx* c, int side, const void* buf) {
 int lbm_step_edges(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->p.device));
-    return launch_step(c, 0, c->geo.ny - 1, 2, c->s_compute);
+    return launch_rows(c, 0, c->geo.ny - 1, 2, c->s_compute);
 }
 
 int lbm_step_interior(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->p.device));
-    return launch_step(c, 1, 1, c->geo.ny - 2, c->s_compute);
+    return launch_rows(c, 1, 1, c->geo.ny - 2, c->s_compute);
 }
 
 int lbm_step_finish(lbm_ctx* c) {
