@@ -59,7 +59,7 @@ def host_cores():
     return int(os.environ.get("LBM_BENCH_CPU_THREADS", min(n, 32)))
 
 
-def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=12.0):
+def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=15.0):
     """The C oracle (oracle/lbm_ref.c, kind 'port') on this host's cores, bounded sample."""
     from oracle import lbm_ref
     threads = max(1, min(lbm_ref.max_threads(), host_cores()))
