@@ -493,4 +493,65 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// S time steps per launch with ONE LDS buffer updated in place (used with S = 3 for fp64, where
+// the bytes saved outweigh the extra arithmetic; for fp32 the two-step kernel above is faster --
+// measured, gpurun_out/tb4.log).  One vector cell per thread: the region is PH = TY + 2(S-1) rows
+// by PW = TX + 2V columns and the workgroup has PH * PW / V threads.  Step 1 pulls from global
+// memory; steps 2..S pull from LDS into registers, wait for everyone, compute, and overwrite
+// their own slot; the region that is still valid shrinks by one cell per step (the V-wide rim in
+// x allows up to V + 1 steps).  Threads outside the valid region compute garbage that nobody uses.
+// ------------------------------------------------------------------------------------------
+template <typename R, int COLL, int V, int TX, int TY, int S>
+__device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
+                                                    const Relax<R>& w, R* __restrict__ lds, int tx0, int ty0, int xe, int ye) {
+    typedef typename VecT<R, V>::type T;
+    constexpr int PW = TX + 2 * V, PH = TY + 2 * (S - 1), PVC = PW / V;
+    static_assert(S - 1 <= V, "the x rim is only V cells wide");
+    const int r = threadIdx.x / PVC, vc = threadIdx.x % PVC;
+    const int x0 = tx0 - V + vc * V, y = ty0 - (S - 1) + r;
+    T in[Q], outv[Q], hq, hr;
+    const bool inside = x0 < geo.nx && y < geo.ny;
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k)
+            in[k] = vload<R, V, false>(src + k * geo.plane + geo.at(x0 - cxk(k), y + cyk(k)), cxk(k) == 0);
+        collide_vec<R, COLL, V, false>(in, w, outv, hq, hr);
+    }
+#pragma unroll
+    for (int s = 2; s <= S; ++s) {
+        if (inside) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) *reinterpret_cast<T*>(lds + ((k * PH + r) * PW + vc * V)) = outv[k];
+        }
+        __syncthreads();
+        const bool act = r >= s - 1 && r < PH - (s - 1);
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                const R* p = lds + ((k * PH + (r + cyk(k))) * PW + vc * V);
+                const T own = *reinterpret_cast<const T*>(p);
+                if (cxk(k) == 0) {
+                    in[k] = own;
+                } else if (cxk(k) > 0) {
+                    in[k][0] = p[-1];
+#pragma unroll
+                    for (int c = 1; c < V; ++c) in[k][c] = own[c - 1];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < V - 1; ++c) in[k][c] = own[c + 1];
+                    in[k][V - 1] = p[V];
+                }
+            }
+        }
+        if (s < S) __syncthreads();   // everyone has read before anyone overwrites in place
+        if (act) collide_vec<R, COLL, V, false>(in, w, outv, hq, hr);
+    }
+    if (r >= S - 1 && r < PH - (S - 1) && vc >= 1 && vc < PVC - 1 && x0 < xe && y < ye) {
+        const long long me = geo.at(x0, y);
+#pragma unroll
+        for (int k = 0; k < Q; ++k) vstore<R, V, false>(dst + k * geo.plane + me, outv[k]);
+    }
+}
+
 }  // namespace lbm

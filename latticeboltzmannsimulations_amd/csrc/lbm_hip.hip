@@ -65,7 +65,6 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
 
 // ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
 constexpr int TB_F = 4;      // cells within TB_F of a wall / slab edge are advanced by single steps
-constexpr int TB_G = 6;      // ... and the first of the two single steps covers TB_G cells
 constexpr int TB_NT = 512;   // threads per tile
 // Tile shape (measured sweep, gpurun_out/tb2.log, tb3.log): wide and short wins -- 62 vectors (248 fp32 / 124 fp64 cells)
 // x 6 rows: phase 1 is 8 rows x 64 vectors = exactly one vector cell per thread and one wave per 1-KiB row segment
@@ -83,6 +82,20 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
     const int per = ntiles >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);   // every XCD walks its own band of tile rows
     update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
+}
+
+// Three steps per launch (fp64): 60 x 12 tile, region 16 rows x 32 vectors = 512 threads, 72 KiB of LDS.
+constexpr int TB3_TXV = 30, TB3_TY = 12;
+template <typename R, int COLL>
+__global__ __launch_bounds__(512) void k_step3_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+                                                    int xe, int ye, int ntx, int ntiles) {
+    constexpr int V = 16 / (int)sizeof(R), TX = TB3_TXV * V, TY = TB3_TY, PW = TX + 2 * V, PH = TY + 4;
+    static_assert(PH * PW / V == 512, "one vector cell per thread");
+    __shared__ __align__(16) R lds_raw[Q * PH * PW + 2 * V];   // one vector of slack at each end: rim columns read one
+    int b = blockIdx.x;                                         // element past their row
+    const int per = ntiles >> 3;
+    if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
+    update_tile_inplace<R, COLL, V, TX, TY, 3>(src, dst, geo, w, lds_raw + V, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
 // One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
@@ -190,7 +203,7 @@ struct lbm_ctx {
     lbm_params p{};
     int es = 0;  // element size
     Geo geo{};
-    void* lat[3] = {nullptr, nullptr, nullptr};   // [0], [1]: the two lattices; [2]: frame scratch of the double step
+    void* lat[4] = {nullptr, nullptr, nullptr, nullptr};   // [0], [1]: the two lattices; [2], [3]: frame scratch of the multi-step
     int raw[2] = {1, 1};
     int cur = 0;  // lat[cur] is the source of the next step
     long long nsteps = 0;
@@ -205,6 +218,7 @@ struct lbm_ctx {
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
+    int tb_steps = 2;           // ... or three (fp64 without the Smagorinsky closure)
     std::string err;
 };
 
@@ -349,13 +363,20 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s) {
     return LBM_OK;
 }
 
-// Two steps on the deep interior, lat[from] -> lat[to].
+// c->tb_steps steps on the deep interior, lat[from] -> lat[to].
 int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
-        constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<VT::TURB>() * V, TY = tb_ty<VT::TURB>();
         const int xe = c->geo.nx - TB_F, ye = c->geo.ny - TB_F;
+        if (c->tb_steps == 3) {
+            constexpr int V = 16 / (int)sizeof(R), TX = TB3_TXV * V;
+            const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TB3_TY - 1) / TB3_TY;
+            hipLaunchKernelGGL((k_step3_deep<R, VT::COLL>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from], (R*)c->lat[to],
+                               c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
+            return;
+        }
+        constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<VT::TURB>() * V, TY = tb_ty<VT::TURB>();
         const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
         hipLaunchKernelGGL((k_step2_deep<R, VT::COLL, VT::TURB>), dim3(ntx * nty), dim3(TB_NT), 0, s, (const R*)c->lat[from],
                            (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
@@ -480,26 +501,30 @@ int single_step(lbm_ctx* c, bool* comm_used) {
     return LBM_OK;
 }
 
-// Two steps: lat[a] (state n) -> lat[b] (state n+2).  Bulk: k_step2_deep on cells >= TB_F away from walls and slab
-// edges.  Frame: two ordinary single steps on strips, n -> n+1 into the scratch lattice (width TB_G), n+1 -> n+2 into
-// lat[b] (width TB_F); between slabs each of the two needs its own halo, so there are two exchanges per double step.
-int double_step(lbm_ctx* c, bool* comm_used) {
+// S = c->tb_steps steps: lat[a] (state n) -> lat[b] (state n+S).  Bulk: the deep-interior kernel on cells >= TB_F away
+// from walls and slab edges.  Frame: S ordinary single steps on strips of decreasing width (TB_F + S - i for pass i; pass i+1
+// pulls from one cell further out than it writes), through the scratch lattices, the last one into lat[b].  Between slabs
+// every pass needs its own halo, so there are S exchanges per multi-step.
+int multi_step(lbm_ctx* c, bool* comm_used) {
     const bool multi = c->nranks > 1 || c->loopback;
-    const int a = c->cur, b = c->cur ^ 1, t = 2;
+    const int S = c->tb_steps, a = c->cur, b = c->cur ^ 1;
     HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
     int rc;
     if (multi && !c->halo_pending) {
         rc = enqueue_exchange(c, a);
         if (rc) return rc;
     }
-    rc = launch_frame(c, a, t, TB_G, c->s_comm);
-    if (rc) return rc;
-    if (multi) {
-        rc = enqueue_exchange(c, t);
+    int from = a;
+    for (int i = 1; i <= S; ++i) {
+        const int to = i == S ? b : 2 + ((i - 1) & 1);
+        rc = launch_frame(c, from, to, TB_F + S - i, c->s_comm);
         if (rc) return rc;
+        if (multi && i < S) {
+            rc = enqueue_exchange(c, to);
+            if (rc) return rc;
+        }
+        from = to;
     }
-    rc = launch_frame(c, t, b, TB_F, c->s_comm);
-    if (rc) return rc;
     HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
     HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
     rc = launch_deep(c, a, b, c->s_compute);
@@ -507,7 +532,7 @@ int double_step(lbm_ctx* c, bool* comm_used) {
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
     c->cur ^= 1;
     c->raw[c->cur] = 0;
-    c->nsteps += 2;
+    c->nsteps += S;
     if (multi) {
         rc = enqueue_exchange(c, c->cur);
         if (rc) return rc;
@@ -526,7 +551,7 @@ int step_many(lbm_ctx* c, int nsteps) {
         // The first step after an upload reads raw populations, and the LAST step of a call is always a single step:
         // lbm_get_fields needs the lattice of the step before the last for the one-step lag of u / rho.
         int rc;
-        if (c->use_tb && !c->raw[c->cur] && left >= 3) { rc = double_step(c, &comm_used); left -= 2; }
+        if (c->use_tb && !c->raw[c->cur] && left >= c->tb_steps + 1) { rc = multi_step(c, &comm_used); left -= c->tb_steps; }
         else { rc = single_step(c, &comm_used); left -= 1; }
         if (rc) return rc;
     }
@@ -671,6 +696,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // a double step do not pay
         const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
+        // three steps per launch pay for fp64 (94 vs 75 GLUPS at 4096^2), not for fp32 (134 vs 141): gpurun_out/tb4.log
+        const char* ts = std::getenv("LBM_TB_STEPS");
+        c->tb_steps = ts ? std::atoi(ts) : (p->dtype == LBM_F64 && p->turb == 0 ? 3 : 2);
+        if (c->tb_steps != 3 || p->turb != 0) c->tb_steps = 2;
         const char* nt = std::getenv("LBM_NT");
         c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
     }
@@ -687,7 +716,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
-    for (int i = 0; i < (c->use_tb ? 3 : 2); ++i) {
+    for (int i = 0; i < (c->use_tb ? c->tb_steps + 1 : 2); ++i) {
         if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
         // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
         if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
@@ -702,7 +731,7 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->s_compute) (void)hipStreamSynchronize(c->s_compute);
     if (c->s_comm) (void)hipStreamSynchronize(c->s_comm);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         if (c->lat[i]) (void)hipFree(c->lat[i]);
     if (c->stage) (void)hipFree(c->stage);
     if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);
