@@ -100,16 +100,19 @@ def _dashboard(path, u, rho, It, hist, Re, RT, regime, BC, xsize, ysize, uLB, re
 
 def run_cavity(maxIt=3000000, Re=10000.0, RT="SRT", turb=1, xsize=32 * 5, ysize=32 * 5, uLB=0.08,
                Pinterval=3000, SavePlot=True, SaveVTK=False, project="ldc", OutputFolder="./output",
-               dtype=np.float32, semantics="mrt_gpu", device=0, quiet=False):
+               dtype=np.float32, semantics="mrt_gpu", device=0, quiet=False, solver_factory=None):
     """Run the lid-driven cavity like MRT_GPU.py does; returns a :class:`CavityResult`.
 
     Argument names and defaults are the module constants of MRT_GPU.py:38-58.
-    xsize / ysize need not be multiples of 32 here."""
+    xsize / ysize need not be multiples of 32 here.  `solver_factory` (default: CavitySolver, i.e. liblbm_hip.so)
+    exists so that this driver logic -- output iterations, metrics, files, convergence stop -- can be unit-tested
+    with a stand-in stepper; it is not a fallback: nothing in this package provides another stepper."""
     say = (lambda *a: None) if quiet else print
     tstart = timer()
     say("the value of uLB is ", uLB)
     say("xsize value is ", xsize)
-    solver = CavitySolver(xsize, ysize, Re, RT=RT, uLB=uLB, semantics=semantics, dtype=dtype, turb=turb, device=device)
+    make = CavitySolver if solver_factory is None else solver_factory
+    solver = make(xsize, ysize, Re, RT=RT, uLB=uLB, semantics=semantics, dtype=dtype, turb=turb, device=device)
     relax = solver.relax
     say("Re chosen  is ", Re)
     say("RT chosen is ", RT)

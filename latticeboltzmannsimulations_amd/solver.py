@@ -144,6 +144,23 @@ class CavitySolver:
                     "lbm_get_fields")
         return (u, rho, fin) if fin is not None else (u, rho)
 
+    # -- checkpoint / restart (the reference has neither) -------------------
+    def save_checkpoint(self, path):
+        """Write the populations and the run parameters to `path` (.npz).  Restarting from it continues bit-identically
+        (the state of the scheme is `fin`); with turb = 1 the one-step Smagorinsky history restarts from the state."""
+        u, rho, fin = self.get_fields(want_fin=True)
+        np.savez(path, fin=fin, steps_done=self.steps_done, nx=self.nx, ny=self.ny, Re=self.Re, RT=self.RT, uLB=self.uLB,
+                 semantics=self.semantics, dtype=self.dtype.name, u=u, rho=rho)
+
+    def load_checkpoint(self, path):
+        """Upload the populations of a checkpoint written by save_checkpoint (sizes must match); returns the number of
+        steps the checkpointed run had done."""
+        with np.load(path, allow_pickle=False) as z:
+            if int(z["nx"]) != self.nx or int(z["ny"]) != self.ny:
+                raise ValueError("checkpoint lattice size differs")
+            self.set_state(np.ascontiguousarray(z["fin"]))
+            return int(z["steps_done"])
+
     # -- slab exchange primitives ---------------------------------------------------------
     def halo_elems(self):
         return int(self.lib.lbm_halo_elems(self._h))

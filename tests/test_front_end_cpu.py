@@ -1,0 +1,77 @@
+"""CPU test of the drop-in front end's HOST logic (mrt_gpu.run_cavity: which iterations produce output, the
+reference's metric and prints, PNG / VTK files, convergence stop) with a stand-in stepper backed by the oracle.
+The product has no CPU stepper; the stand-in lives here, in tests/."""
+import os
+
+import numpy as np
+import pytest
+
+from latticeboltzmannsimulations_amd import relaxation
+from latticeboltzmannsimulations_amd.mrt_gpu import run_cavity
+from oracle.lbm_ref import CavityOracleC
+
+
+class OracleStepper:
+    """Same surface as CavitySolver as far as run_cavity uses it."""
+    calls = []
+
+    def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0, device=0):
+        self.o = CavityOracleC(xsize, ysize, Re, uLB=uLB, semantics=semantics, collision=RT, dtype=dtype, turb=turb)
+        self.relax = relaxation(Re, ysize, uLB)
+        OracleStepper.calls = []
+
+    def step(self, n=1):
+        OracleStepper.calls.append(int(n))
+        self.o.step(n)
+        return self
+
+    def sync(self):
+        pass
+
+    def get_fields(self, out_dtype=None, **kw):
+        return self.o.u.astype(out_dtype), self.o.rho.astype(out_dtype)
+
+    def close(self):
+        pass
+
+
+def test_output_iterations_batches_and_files(tmp_path, monkeypatch, capsys):
+    monkeypatch.chdir(tmp_path)
+    r = run_cavity(maxIt=251, Re=100.0, RT="SRT", turb=1, xsize=32, ysize=32, Pinterval=100, SavePlot=True, SaveVTK=True,
+                   solver_factory=OracleStepper)
+    # iteration 0 alone, then batches up to every multiple of Pinterval, then the remainder (no output after it)
+    assert OracleStepper.calls == [1, 100, 100, 50]
+    assert r.iterations == 251 and [it for it, _ in r.regression] == [0, 100, 200]
+    for i in range(3):
+        assert os.path.exists(tmp_path / "output" / f"ldc_{i:05d}.png")
+        assert os.path.exists(tmp_path / "output" / f"ldc.{i:05d}.vtr")
+    out = capsys.readouterr().out
+    for line in ("the value of uLB is  0.08", "xsize value is  32", "RT chosen is  SRT", "Turbulence is on",
+                 "current iteration : 200", "current regression value is ", "time elapsed is ", "TOTAL time elapsed is "):
+        assert line in out
+    assert "max iterations reached" not in out          # 250 is not an output iteration
+    o = CavityOracleC(32, 32, 100.0, semantics="mrt_gpu", collision="SRT", dtype=np.float32, turb=1).step(251)
+    assert np.array_equal(r.u, o.u) and r.u.dtype == np.float32
+
+
+def test_convergence_stop(tmp_path, monkeypatch, capsys):
+    """MRT_GPU.py:883-889: |mean(u) - mean(u_past)| / uLB < 1e-8 on more than five output iterations ends the run."""
+    monkeypatch.chdir(tmp_path)
+    r = run_cavity(maxIt=10 ** 7, Re=100.0, RT="MRT", turb=0, xsize=16, ysize=16, Pinterval=400, SavePlot=False, SaveVTK=True,
+                   dtype=np.float64, solver_factory=OracleStepper)
+    assert r.converged and r.iterations < 10 ** 6
+    assert "breaking out of loop because of convergence" in capsys.readouterr().out
+
+
+def test_no_output_flags_means_one_batch(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    r = run_cavity(maxIt=37, Re=400.0, RT="TRT", turb=0, xsize=16, ysize=16, Pinterval=10, SavePlot=False, SaveVTK=False,
+                   quiet=True, solver_factory=OracleStepper)
+    assert OracleStepper.calls == [37] and r.regression == [] and not os.path.exists(tmp_path / "output")
+
+
+def test_unknown_reynolds_number_has_no_ghia_column(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    r = run_cavity(maxIt=11, Re=250.0, RT="SRT", turb=0, xsize=16, ysize=16, Pinterval=5, SavePlot=True, SaveVTK=False,
+                   quiet=True, solver_factory=OracleStepper)
+    assert r.regression == [] and r.iterations == 11
