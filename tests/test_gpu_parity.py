@@ -223,6 +223,24 @@ def test_set_state_roundtrip_and_exact_restart(sem):
         assert np.array_equal(back, fin25.astype(np.float32).astype(np.float64))
 
 
+def test_reynolds_sweep_datagen(tmp_path):
+    """datagen.generate (MRT_GPU_datagen.py): concurrent lattices == each solved alone by the oracle; file set."""
+    from latticeboltzmannsimulations_amd.datagen import generate
+    Re = np.array([100, 400, 1000, 2500])
+    feq0, f_final, u_final, Re_out, its = generate(Re, xsize=48, ysize=48, maxIt=2500, Pinterval=400, concurrent=3,
+                                                   OutputFolder=str(tmp_path / "out"), quiet=True)
+    assert f_final.shape == (4, 9, 48, 48) and u_final.shape == (4, 2, 48, 48) and np.array_equal(Re_out, Re)
+    for name in ("feq_initial.npy", "f_final.npy", "u_final.npy", "Re_range.npy"):
+        assert os.path.exists(tmp_path / "out" / name)
+    assert np.array_equal(np.load(tmp_path / "out" / "f_final.npy"), f_final)
+    for i, re in enumerate(Re):
+        o = CavityOracleC(48, 48, float(re), semantics="mrt_gpu", collision="SRT", dtype=np.float32, turb=1)
+        assert np.array_equal(feq0, o.fin)
+        o.step(int(its[i]))
+        assert np.array_equal(f_final[i], o.fin) and np.array_equal(u_final[i], o.u), re
+    assert (its == 2500).all()          # not converged within maxIt at tolerance 1e-7: the loop ran to its end
+
+
 def test_checkpoint_restart(tmp_path):
     with CavitySolver(96, 64, 400.0, RT="MRT", dtype=np.float64) as a:
         a.step(40)
