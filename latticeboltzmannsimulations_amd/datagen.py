@@ -13,6 +13,7 @@ streams (and, with `devices`, spread over several GPUs of the node): their kerne
 bit-identical to running it alone.
 """
 import os
+from concurrent.futures import ThreadPoolExecutor
 from timeit import default_timer as timer
 
 import numpy as np
@@ -22,7 +23,7 @@ from .solver import CavitySolver
 
 def generate(Re_range=None, xsize=32 * 12, ysize=32 * 12, RT="SRT", turb=1, uLB=0.08, maxIt=3000000, Pinterval=10000,
              tolerance=0.0000001, OutputFolder="./output", save=True, concurrent=16, devices=(0,), dtype=np.float32,
-             quiet=False):
+             quiet=False, host_threads=4):
     """Returns (feq_initial, f_final, u_final, Re_range, iterations_per_Re); writes the four .npy files when `save`."""
     say = (lambda *a: None) if quiet else print
     Re_range = np.arange(100, 5100, 10) if Re_range is None else np.asarray(Re_range)   # MRT_GPU_datagen.py:55
@@ -34,6 +35,7 @@ def generate(Re_range=None, xsize=32 * 12, ysize=32 * 12, RT="SRT", turb=1, uLB=
     feq_initial = None
     pending = list(range(n))
     active = []          # [index, solver, count, u_past_mean, next_It]
+    pool = ThreadPoolExecutor(max_workers=min(concurrent, host_threads)) if host_threads > 1 else None
     while pending or active:
         while pending and len(active) < concurrent:
             i = pending.pop(0)
@@ -42,9 +44,16 @@ def generate(Re_range=None, xsize=32 * 12, ysize=32 * 12, RT="SRT", turb=1, uLB=
             if feq_initial is None:
                 feq_initial = s.get_fields(want_fin=True, out_dtype=np.float32)[2]     # fin = equ(1, InitVel) = feq_initial
             active.append([i, s, 0, 0.0, 0])
-        # enqueue, for every active lattice, the iterations up to its next check (asynchronous); then collect
-        for a in active:
+        # enqueue, for every active lattice, the iterations up to its next check; then collect.  One host thread per
+        # lattice: lbm_step loops over thousands of launches in C (ctypes releases the GIL), and a single thread would
+        # finish enqueuing lattice A before starting on B, leaving nothing to overlap on the device.
+        def advance(a):
             a[1].step(a[4] + 1 - a[1].steps_done)          # the check of iteration It happens after It + 1 steps
+        if pool is not None and len(active) > 1:
+            list(pool.map(advance, active))
+        else:
+            for a in active:
+                advance(a)
         still = []
         for a in active:
             i, s, count, past, It = a
@@ -70,6 +79,8 @@ def generate(Re_range=None, xsize=32 * 12, ysize=32 * 12, RT="SRT", turb=1, uLB=
             else:
                 still.append([i, s, count, mean_u, It + Pinterval])
         active = still
+    if pool is not None:
+        pool.shutdown()
     if save:
         if not os.path.isdir(OutputFolder):
             os.makedirs(OutputFolder, exist_ok=True)
