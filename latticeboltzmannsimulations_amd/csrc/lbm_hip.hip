@@ -84,7 +84,8 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
     update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
-// Three steps per launch (fp64): 60 x 12 tile, region 16 rows x 32 vectors = 512 threads, 72 KiB of LDS.
+// Three steps per launch: 30 vectors (120 fp32 / 60 fp64 cells) x 12 rows, region 16 rows x 32 vectors = 512 threads,
+// 72 KiB of LDS.
 constexpr int TB3_TXV = 30, TB3_TY = 12;
 template <typename R, int COLL>
 __global__ __launch_bounds__(512) void k_step3_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
@@ -696,10 +697,11 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // a double step do not pay
         const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
-        // three steps per launch pay for fp64 (94 vs 75 GLUPS at 4096^2), not for fp32 (134 vs 141): gpurun_out/tb4.log
+        // three steps per launch (in-place LDS tile) beat two for both precisions in the full stepper -- 4096^2 fp32 MRT
+        // 170 vs 140 GLUPS, fp64 99 vs 75 (gpurun_out/perf11.log); with the Smagorinsky history planes only the
+        // two-step tile fits two workgroups per CU.  LBM_TB_STEPS=2 forces two (A/B, tests).
         const char* ts = std::getenv("LBM_TB_STEPS");
-        c->tb_steps = ts ? std::atoi(ts) : (p->dtype == LBM_F64 && p->turb == 0 ? 3 : 2);
-        if (c->tb_steps != 3 || p->turb != 0) c->tb_steps = 2;
+        c->tb_steps = (p->turb == 0 && !(ts && std::atoi(ts) == 2)) ? 3 : 2;
         const char* nt = std::getenv("LBM_NT");
         c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
     }

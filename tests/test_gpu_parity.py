@@ -113,12 +113,13 @@ def test_two_steps_per_launch_is_bit_identical_to_oracle(sem, coll, dtype):
             same(s, o, "tb after set_state")
 
 
-def test_fp64_multi_step_variants_agree(monkeypatch):
-    """fp64 advances three steps per launch by default (two with LBM_TB_STEPS=2): same bits either way."""
-    o = CavityOracleC(132, 99, 400.0, semantics="mrt_gpu", collision="MRT").step(47)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_and_three_steps_per_launch_agree(monkeypatch, dtype):
+    """The interior advances three steps per launch by default (two with LBM_TB_STEPS=2): same bits either way."""
+    o = CavityOracleC(132, 99, 400.0, semantics="mrt_gpu", collision="MRT", dtype=dtype).step(47)
     for steps in ("2", "3"):
         monkeypatch.setenv("LBM_TB_STEPS", steps)
-        with CavitySolver(132, 99, 400.0, RT="MRT", dtype=np.float64, kernel="tb") as s:
+        with CavitySolver(132, 99, 400.0, RT="MRT", dtype=dtype, kernel="tb") as s:
             s.step(47)
             same(s, o, f"LBM_TB_STEPS={steps}")
 
