@@ -545,7 +545,8 @@ __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R
             }
         }
         if (s < S) __syncthreads();   // everyone has read before anyone overwrites in place
-        if (act) collide_vec<R, COLL, V, false>(in, w, outv, hq, hr);
+        // (the rim columns are needed by the next step but not after the last one)
+        if (act && (s < S || (vc >= 1 && vc < PVC - 1))) collide_vec<R, COLL, V, false>(in, w, outv, hq, hr);
     }
     if (r >= S - 1 && r < PH - (S - 1) && vc >= 1 && vc < PVC - 1 && x0 < xe && y < ye) {
         const long long me = geo.at(x0, y);

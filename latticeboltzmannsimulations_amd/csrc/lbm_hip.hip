@@ -84,13 +84,14 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
     update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
-// Three steps per launch: 30 vectors (120 fp32 / 60 fp64 cells) x 12 rows, region 16 rows x 32 vectors = 512 threads,
-// 72 KiB of LDS.
-constexpr int TB3_TXV = 30, TB3_TY = 12;
-template <typename R, int COLL>
+// Three steps per launch: region of 512 vector cells = one per thread, 72 KiB of LDS.  WIDE: 30 vectors (120 fp32 / 60 fp64
+// cells) x 12 rows (region 32 x 16); otherwise 14 vectors x 28 rows (region 16 x 32: less rim work, shorter row segments).
+template <bool WIDE> constexpr int tb3_txv() { return WIDE ? 30 : 14; }
+template <bool WIDE> constexpr int tb3_ty() { return WIDE ? 12 : 28; }
+template <typename R, int COLL, bool WIDE>
 __global__ __launch_bounds__(512) void k_step3_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                     int xe, int ye, int ntx, int ntiles) {
-    constexpr int V = 16 / (int)sizeof(R), TX = TB3_TXV * V, TY = TB3_TY, PW = TX + 2 * V, PH = TY + 4;
+    constexpr int V = 16 / (int)sizeof(R), TX = tb3_txv<WIDE>() * V, TY = tb3_ty<WIDE>(), PW = TX + 2 * V, PH = TY + 4;
     static_assert(PH * PW / V == 512, "one vector cell per thread");
     __shared__ __align__(16) R lds_raw[Q * PH * PW + 2 * V];   // one vector of slack at each end: rim columns read one
     int b = blockIdx.x;                                         // element past their row
@@ -219,7 +220,8 @@ struct lbm_ctx {
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
-    int tb_steps = 2;           // ... or three (fp64 without the Smagorinsky closure)
+    int tb_steps = 2;           // ... or three (without the Smagorinsky closure)
+    bool tb3_wide = false;      // tile shape of the three-step kernel: 30 vectors x 12 rows instead of 14 x 28
     std::string err;
 };
 
@@ -371,10 +373,18 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
         using R = typename VT::R;
         const int xe = c->geo.nx - TB_F, ye = c->geo.ny - TB_F;
         if (c->tb_steps == 3) {
-            constexpr int V = 16 / (int)sizeof(R), TX = TB3_TXV * V;
-            const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TB3_TY - 1) / TB3_TY;
-            hipLaunchKernelGGL((k_step3_deep<R, VT::COLL>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from], (R*)c->lat[to],
-                               c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
+            constexpr int V = 16 / (int)sizeof(R);
+            if (c->tb3_wide) {
+                constexpr int TX = tb3_txv<true>() * V, TY = tb3_ty<true>();
+                const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
+                hipLaunchKernelGGL((k_step3_deep<R, VT::COLL, true>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
+                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
+            } else {
+                constexpr int TX = tb3_txv<false>() * V, TY = tb3_ty<false>();
+                const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
+                hipLaunchKernelGGL((k_step3_deep<R, VT::COLL, false>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
+                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
+            }
             return;
         }
         constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<VT::TURB>() * V, TY = tb_ty<VT::TURB>();
@@ -702,6 +712,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // two-step tile fits two workgroups per CU.  LBM_TB_STEPS=2 forces two (A/B, tests).
         const char* ts = std::getenv("LBM_TB_STEPS");
         c->tb_steps = (p->turb == 0 && !(ts && std::atoi(ts) == 2)) ? 3 : 2;
+        // tile shape of the three-step kernel, A/B in one run (gpurun_out/perf14.log): 14 vectors x 28 rows beats
+        // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  LBM_TB3_WIDE=1 selects 30 x 12.
+        const char* shp = std::getenv("LBM_TB3_WIDE");
+        c->tb3_wide = shp && std::atoi(shp) != 0;
         const char* nt = std::getenv("LBM_NT");
         c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
     }
