@@ -131,7 +131,7 @@ def main():
             dist.barrier()
 
     # Device wake-up, identical for every N: ~40 ms of plain HBM copies so that clocks and power state are those of a
-    # loaded device before anything is timed (a cold first 200-step window reads ~10 % low: gpurun_out/perf12.log).
+    # loaded device before anything is timed (a cold first 200-step window reads ~10 % low: profiles/r01_logs/perf12.log).
     # These are not workload steps; the W warm-up steps of the contract follow.
     wake_gbps = solver.copy_bandwidth(1 << 30, 100)
     solver.step(a.warmup)

@@ -494,9 +494,8 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// S time steps per launch with ONE LDS buffer updated in place (used with S = 3 for fp64, where
-// the bytes saved outweigh the extra arithmetic; for fp32 the two-step kernel above is faster --
-// measured, gpurun_out/tb4.log).  One vector cell per thread: the region is PH = TY + 2(S-1) rows
+// S time steps per launch with ONE LDS buffer updated in place (used with S = 3, the default
+// without the Smagorinsky closure: profiles/r01_logs/perf11.log).  One vector cell per thread: the region is PH = TY + 2(S-1) rows
 // by PW = TX + 2V columns and the workgroup has PH * PW / V threads.  Step 1 pulls from global
 // memory; steps 2..S pull from LDS into registers, wait for everyone, compute, and overwrite
 // their own slot; the region that is still valid shrinks by one cell per step (the V-wide rim in

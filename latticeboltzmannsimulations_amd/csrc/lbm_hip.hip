@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
 // ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
 constexpr int TB_F = 4;      // cells within TB_F of a wall / slab edge are advanced by single steps
 constexpr int TB_NT = 512;   // threads per tile
-// Tile shape (measured sweep, gpurun_out/tb2.log, tb3.log): wide and short wins -- 62 vectors (248 fp32 / 124 fp64 cells)
+// Tile shape (measured sweep, profiles/r01_logs/tb2.log, tb3.log): wide and short wins -- 62 vectors (248 fp32 / 124 fp64 cells)
 // x 6 rows: phase 1 is 8 rows x 64 vectors = exactly one vector cell per thread and one wave per 1-KiB row segment
 // (9 x 8 x 256 x 4 B = 72 KiB of LDS: two tiles per CU).  The row re-reads of the short tile are served by L2.
 // With the two Smagorinsky history planes: 30 vectors x 12 rows (11 x 14 x 128 x 4 B = 77 KiB).
@@ -703,16 +703,16 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC;
         const bool can_tb = p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
         if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
-        // measured crossover (gpurun_out/perf4.log): below ~768^2 cells a step is launch-bound and the three launches of
+        // measured crossover (profiles/r01_logs/perf4.log): below ~768^2 cells a step is launch-bound and the three launches of
         // a double step do not pay
         const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
         // three steps per launch (in-place LDS tile) beat two for both precisions in the full stepper -- 4096^2 fp32 MRT
-        // 170 vs 140 GLUPS, fp64 99 vs 75 (gpurun_out/perf11.log); with the Smagorinsky history planes only the
+        // 170 vs 140 GLUPS, fp64 99 vs 75 (profiles/r01_logs/perf11.log); with the Smagorinsky history planes only the
         // two-step tile fits two workgroups per CU.  LBM_TB_STEPS=2 forces two (A/B, tests).
         const char* ts = std::getenv("LBM_TB_STEPS");
         c->tb_steps = (p->turb == 0 && !(ts && std::atoi(ts) == 2)) ? 3 : 2;
-        // tile shape of the three-step kernel, A/B in one run (gpurun_out/perf14.log): 14 vectors x 28 rows beats
+        // tile shape of the three-step kernel, A/B in one run (profiles/r01_logs/perf14.log): 14 vectors x 28 rows beats
         // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  LBM_TB3_WIDE=1 selects 30 x 12.
         const char* shp = std::getenv("LBM_TB3_WIDE");
         c->tb3_wide = shp && std::atoi(shp) != 0;
