@@ -125,10 +125,10 @@ def test_two_and_three_steps_per_launch_agree(monkeypatch, dtype):
 
 
 def test_seeded_random_configurations_against_oracle():
-    """30 seeded random (size, steps, semantics, collision, dtype, kernel, layout, turb) draws; every kernel variant must
+    """40 seeded random (size, steps, semantics, collision, dtype, kernel, layout, turb) draws; every kernel variant must
     reproduce the oracle bit for bit, including ragged sizes and step counts that mix 1-, 2- and 3-step launches."""
     rng = np.random.default_rng(20261004)
-    for case in range(30):
+    for case in range(40):
         sem = "mrt_gpu" if rng.random() < 0.7 else "mrt_py"
         coll = ["SRT", "TRT", "MRT"][rng.integers(3)]
         dtype = [np.float32, np.float64][rng.integers(2)]
@@ -138,6 +138,9 @@ def test_seeded_random_configurations_against_oracle():
         kernel = ["auto", "generic", "vec", "tb"][rng.integers(4)]
         if sem == "mrt_py" and kernel == "vec":
             kernel = "generic"
+        if kernel in ("auto", "generic") and rng.random() < 0.5:
+            nx = int(rng.integers(9, 333))            # any width: auto falls back to the one-thread-per-cell kernel
+            ny = int(rng.integers(5, 140))
         layout = ["rows", "planes"][rng.integers(2)]
         Re = [100.0, 400.0, 1000.0, 5000.0][rng.integers(4)]
         chunks = [int(v) for v in rng.integers(1, 12, size=3)]
