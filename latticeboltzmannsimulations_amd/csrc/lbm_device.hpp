@@ -25,6 +25,13 @@ struct Relax {  // a2: MRT_GPU.py:63-93
     R uLB, w_nu, w_m, w_e, w_eps, w_q;
 };
 
+// The operators below are written once for a value type T that is either a scalar real or a 2-wide extended vector of
+// reals (two cells side by side): on gfx950 fp32 pairs compile to packed v_pk_add_f32 / v_pk_mul_f32, lane-wise IEEE, so the
+// results are the same bits as the scalar evaluation.  S = ScalarOf<T>::type is the type of the constants.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct ScalarOf { typedef T type; };
+template <> struct ScalarOf<f32x2> { typedef float type; };
+
 // Destination window of direction k (a7).  SEM_PY: the truncated slices of MRT.py:404-414;
 // SEM_GPU: "neighbour inside the lattice", MRT_GPU.py:412.  gy is the GLOBAL row.
 template <int SEM>
@@ -47,8 +54,8 @@ __device__ __forceinline__ bool in_window(int k, int x, int gy, int X, int Y) {
 
 // a3: equilibrium, MRT.py:213-231 / MRT_GPU.py:408-410.  cu is formed without the
 // multiplications by 0 and +-1 of the reference (value-identical in IEEE arithmetic).
-template <typename R>
-__device__ __forceinline__ R cu_of(int k, R ux, R uy) {
+template <typename T>
+__device__ __forceinline__ T cu_of(int k, T ux, T uy) {
     switch (k) {
         case 1: return ux;
         case 2: return uy;
@@ -58,21 +65,22 @@ __device__ __forceinline__ R cu_of(int k, R ux, R uy) {
         case 6: return -ux + uy;
         case 7: return -ux + -uy;
         case 8: return ux + -uy;
-        default: return (R)0;
+        default: return T{};
     }
 }
 template <typename R>
 __device__ __forceinline__ R weight(int k) {
     return k == 0 ? (R)(4.0 / 9.0) : (k < 5 ? (R)(1.0 / 9.0) : (R)(1.0 / 36.));
 }
-template <typename R>
-__device__ __forceinline__ void equ(R rho, R ux, R uy, R (&feq)[Q]) {
-    const R usqr = ux * ux + uy * uy;
-    const R c = (R)1.5 * usqr;
+template <typename T>
+__device__ __forceinline__ void equ(T rho, T ux, T uy, T (&feq)[Q]) {
+    typedef typename ScalarOf<T>::type S;
+    const T usqr = ux * ux + uy * uy;
+    const T c = (S)1.5 * usqr;
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
-        const R cu = cu_of<R>(k, ux, uy);
-        feq[k] = (rho * weight<R>(k)) * ((((R)1. + (R)3.0 * cu) + ((R)4.5 * cu) * cu) - c);
+        const T cu = cu_of<T>(k, ux, uy);
+        feq[k] = (rho * weight<S>(k)) * ((((S)1. + (S)3.0 * cu) + ((S)4.5 * cu) * cu) - c);
     }
 }
 
@@ -94,13 +102,15 @@ __device__ __forceinline__ void macros(const R (&f)[Q], int x, int gy, int X, in
 // MRT MRT_GPU.py:633-655 (m = M f with jx = m3, jy = m5 from the raw populations, the
 // reference's own m_eq polynomial, f* = Minv m).  Zero matrix entries are skipped and the
 // +-1, +-2, +-4 entries of M are exact scalings: value-identical to the dense products.
-template <typename R, int COLL>
-__device__ __forceinline__ void collide(const R (&f)[Q], R rho, const R (&feq)[Q], const Relax<R>& w, R (&out)[Q]) {
+template <typename T, int COLL>
+__device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q],
+                                        const Relax<typename ScalarOf<T>::type>& w, T (&out)[Q]) {
+    typedef typename ScalarOf<T>::type R;   // constants and relaxation rates are scalars
     if (COLL == C_SRT) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) out[k] = f[k] - w.w_nu * (f[k] - feq[k]);
     } else if (COLL == C_TRT) {
-        R fp[Q], fm[Q], ep[Q], em[Q];
+        T fp[Q], fm[Q], ep[Q], em[Q];
         constexpr int pa[4] = {2, 5, 6, 1}, pb[4] = {4, 7, 8, 3};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -110,11 +120,11 @@ __device__ __forceinline__ void collide(const R (&f)[Q], R rho, const R (&feq)[Q
             ep[a] = (R)0.5 * (feq[a] + feq[b]); ep[b] = ep[a];
             em[a] = (R)0.5 * (feq[a] - feq[b]); em[b] = -em[a];
         }
-        fp[0] = f[0]; fm[0] = (R)0; ep[0] = feq[0]; em[0] = (R)0;
+        fp[0] = f[0]; fm[0] = T{}; ep[0] = feq[0]; em[0] = T{};
 #pragma unroll
         for (int k = 0; k < Q; ++k) out[k] = (f[k] - w.w_nu * (fp[k] - ep[k])) - w.w_m * (fm[k] - em[k]);
     } else {
-        R m[Q], meq[Q];
+        T m[Q], meq[Q];
         // rows of M_GS (MRT.py:163-173), left-to-right sums
         m[0] = (((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7]) + f[8];
         m[1] = ((((((((R)-4 * f[0] - f[1]) - f[2]) - f[3]) - f[4]) + (R)2 * f[5]) + (R)2 * f[6]) + (R)2 * f[7]) + (R)2 * f[8];
@@ -125,7 +135,7 @@ __device__ __forceinline__ void collide(const R (&f)[Q], R rho, const R (&feq)[Q
         m[6] = (((((R)-2 * f[2] + (R)2 * f[4]) + f[5]) + f[6]) - f[7]) - f[8];
         m[7] = ((f[1] - f[2]) + f[3]) - f[4];
         m[8] = ((f[5] - f[6]) + f[7]) - f[8];
-        const R jx = m[3], jy = m[5];
+        const T jx = m[3], jy = m[5];
         meq[0] = rho;
         meq[1] = (R)-2.0 * rho + (R)3.0 * (jx * jx + jy * jy);
         meq[2] = ((R)-3.0 * (jx * jx + jy * jy) + rho) + (R)9.0 * (((jx * jx) * jy) * jy);
@@ -406,23 +416,45 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
                                             typename VecT<R, V>::type (&outv)[Q],
                                             typename VecT<R, V>::type& hq, typename VecT<R, V>::type& hr) {
     // hq, hr: Smagorinsky history of the cells (in: previous step, out: this step); untouched unless TURB
+    if constexpr (sizeof(R) == 4 && V == 4 && !TURB) {
+        // fp32: two cells per operation (packed math), same lane-wise IEEE operations as the scalar form below
 #pragma unroll
-    for (int c = 0; c < V; ++c) {
-        R g[Q], out[Q], fe[Q];
+        for (int p = 0; p < 2; ++p) {
+            f32x2 g[Q], out[Q], fe[Q];
 #pragma unroll
-        for (int k = 0; k < Q; ++k) g[k] = in[k][c];
-        Relax<R> w = w0;
-        if (TURB) w.w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
-        const R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
-        if (COLL != C_MRT || TURB) {
-            const R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
-            const R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
-            equ<R>(rho, ux, uy, fe);
+            for (int k = 0; k < Q; ++k) g[k] = p == 0 ? in[k].xy : in[k].zw;
+            const f32x2 rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+            if (COLL != C_MRT) {
+                const f32x2 ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
+                const f32x2 uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
+                equ<f32x2>(rho, ux, uy, fe);
+            }
+            collide<f32x2, COLL>(g, rho, fe, w0, out);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                if (p == 0) outv[k].xy = out[k];
+                else outv[k].zw = out[k];
+            }
         }
-        collide<R, COLL>(g, rho, fe, w, out);
+    } else {
 #pragma unroll
-        for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
-        if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
+        for (int c = 0; c < V; ++c) {
+            R g[Q], out[Q], fe[Q];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) g[k] = in[k][c];
+            Relax<R> w = w0;
+            if (TURB) w.w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
+            const R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+            if (COLL != C_MRT || TURB) {
+                const R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
+                const R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
+                equ<R>(rho, ux, uy, fe);
+            }
+            collide<R, COLL>(g, rho, fe, w, out);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
+            if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
+        }
     }
 }
 
