@@ -150,8 +150,9 @@ def main():
     es = np.dtype(dtype).itemsize
     mlups = cells_total * a.steps / dt / 1e6
     # algorithmic bytes per lattice update = read 9 + write 9 populations = 18 * sizeof(real).
-    # The dominant kernel (k_step3_deep, three time steps per launch) performs 3 updates of every interior cell per launch;
-    # the K timed steps are about K/3 such launches + 1-3 single-step launches, bracketed by HIP events on the compute stream.
+    # The dominant kernel (k_stepS_deep, S = 4 time steps per launch for fp32, 3 for fp64) performs S updates of every interior
+    # cell per launch; the K timed steps are about K/S such launches + 1..S single-step launches, bracketed by HIP events on
+    # the compute stream.
     alg_bytes_step = cells_rank * 2 * 9 * es
     step_ms = ev_ms / a.steps
     achieved = alg_bytes_step / (step_ms * 1e-3) / 1e9
@@ -201,7 +202,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "event_ms_per_step": round(step_ms, 5), "algorithmic_bytes_per_step": alg_bytes_step,
-                         "note": "achieved = algorithmic bytes (18 words per cell update) / HIP-event time; with three time steps "
+                         "note": "achieved = algorithmic bytes (18 words per cell update) / HIP-event time; with several time steps "
                                  "fused per launch through LDS the HBM bytes actually moved (traffic, per step) are below the "
                                  "algorithmic bytes, so achieved can exceed the physical peak"},
         }

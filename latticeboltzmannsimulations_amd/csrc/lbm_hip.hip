@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __
 }
 
 // ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
-constexpr int TB_F = 4;      // cells within TB_F of a wall / slab edge are advanced by single steps
+constexpr int TB_F = 4;      // cells within F of a wall / slab edge are advanced by single steps (8 with four steps per launch)
 constexpr int TB_NT = 512;   // threads per tile
 // Tile shape (measured sweep, profiles/r01_logs/tb2.log, tb3.log): wide and short wins -- 62 vectors (248 fp32 / 124 fp64 cells)
 // x 6 rows: phase 1 is 8 rows x 64 vectors = exactly one vector cell per thread and one wave per 1-KiB row segment
@@ -84,20 +84,19 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
     update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
-// Three steps per launch: region of 512 vector cells = one per thread, 72 KiB of LDS.  WIDE: 30 vectors (120 fp32 / 60 fp64
-// cells) x 12 rows (region 32 x 16); otherwise 14 vectors x 28 rows (region 16 x 32: less rim work, shorter row segments).
-template <bool WIDE> constexpr int tb3_txv() { return WIDE ? 30 : 14; }
-template <bool WIDE> constexpr int tb3_ty() { return WIDE ? 12 : 28; }
-template <typename R, int COLL, bool WIDE>
-__global__ __launch_bounds__(512) void k_step3_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
-                                                    int xe, int ye, int ntx, int ntiles) {
-    constexpr int V = 16 / (int)sizeof(R), TX = tb3_txv<WIDE>() * V, TY = tb3_ty<WIDE>(), PW = TX + 2 * V, PH = TY + 4;
-    static_assert(PH * PW / V == 512, "one vector cell per thread");
+// S = 3 or 4 steps per launch: region of 512 vector cells = one per thread, 72 KiB of LDS.  WIDE: region 32 vectors x 16 rows;
+// otherwise 16 vectors x 32 rows (less rim work, shorter row segments).  The tile is the region minus the rim: V cells
+// left and right, S - 1 rows above and below.  F = frame width (4; 8 for S = 4 in fp32).
+template <typename R, int COLL, int S, bool WIDE>
+__global__ __launch_bounds__(512) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+                                                    int F, int xe, int ye, int ntx, int ntiles) {
+    constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
+    constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
     __shared__ __align__(16) R lds_raw[Q * PH * PW + 2 * V];   // one vector of slack at each end: rim columns read one
     int b = blockIdx.x;                                         // element past their row
     const int per = ntiles >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
-    update_tile_inplace<R, COLL, V, TX, TY, 3>(src, dst, geo, w, lds_raw + V, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
+    update_tile_inplace<R, COLL, V, TX, TY, S>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
 }
 
 // One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
@@ -221,7 +220,8 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
     int tb_steps = 2;           // ... or three (without the Smagorinsky closure)
-    bool tb3_wide = false;      // tile shape of the three-step kernel: 30 vectors x 12 rows instead of 14 x 28
+    bool tb3_wide = false;      // tile shape of the three/four-step kernel: region 32 vectors x 16 rows instead of 16 x 32
+    int tb_f = TB_F;            // frame width
     std::string err;
 };
 
@@ -371,24 +371,35 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
-        const int xe = c->geo.nx - TB_F, ye = c->geo.ny - TB_F;
-        if (c->tb_steps == 3) {
+        const int F = c->tb_f, xe = c->geo.nx - F, ye = c->geo.ny - F;
+        if (c->tb_steps >= 3) {
             constexpr int V = 16 / (int)sizeof(R);
-            if (c->tb3_wide) {
-                constexpr int TX = tb3_txv<true>() * V, TY = tb3_ty<true>();
-                const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
-                hipLaunchKernelGGL((k_step3_deep<R, VT::COLL, true>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
-                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
-            } else {
-                constexpr int TX = tb3_txv<false>() * V, TY = tb3_ty<false>();
-                const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
-                hipLaunchKernelGGL((k_step3_deep<R, VT::COLL, false>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
-                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
+            auto go = [&](auto steps, auto wide) {
+                constexpr int S = decltype(steps)::value;
+                constexpr bool WIDE = decltype(wide)::value;
+                constexpr int PVC = WIDE ? 32 : 16, TX = (PVC - 2) * V, TY = 512 / PVC - 2 * (S - 1);
+                const int ntx = (xe - F + TX - 1) / TX, nty = (ye - F + TY - 1) / TY;
+                hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, S, WIDE>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
+                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), F, xe, ye, ntx, ntx * nty);
+            };
+            if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
+                if (c->tb_steps == 4) {
+                    if (c->tb3_wide) go(std::integral_constant<int, 4>{}, std::true_type{});
+                    else go(std::integral_constant<int, 4>{}, std::false_type{});
+                    return;
+                }
+                if (c->tb_steps == 5) {
+                    if (c->tb3_wide) go(std::integral_constant<int, 5>{}, std::true_type{});
+                    else go(std::integral_constant<int, 5>{}, std::false_type{});
+                    return;
+                }
             }
+            if (c->tb3_wide) go(std::integral_constant<int, 3>{}, std::true_type{});
+            else go(std::integral_constant<int, 3>{}, std::false_type{});
             return;
         }
         constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<VT::TURB>() * V, TY = tb_ty<VT::TURB>();
-        const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;
+        const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;   // two steps: F = TB_F
         hipLaunchKernelGGL((k_step2_deep<R, VT::COLL, VT::TURB>), dim3(ntx * nty), dim3(TB_NT), 0, s, (const R*)c->lat[from],
                            (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
     });
@@ -528,7 +539,7 @@ int multi_step(lbm_ctx* c, bool* comm_used) {
     int from = a;
     for (int i = 1; i <= S; ++i) {
         const int to = i == S ? b : 2 + ((i - 1) & 1);
-        rc = launch_frame(c, from, to, TB_F + S - i, c->s_comm);
+        rc = launch_frame(c, from, to, c->tb_f + S - i, c->s_comm);
         if (rc) return rc;
         if (multi && i < S) {
             rc = enqueue_exchange(c, to);
@@ -707,11 +718,15 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // a double step do not pay
         const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
-        // three steps per launch (in-place LDS tile) beat two for both precisions in the full stepper -- 4096^2 fp32 MRT
-        // 170 vs 140 GLUPS, fp64 99 vs 75 (profiles/r01_logs/perf11.log); with the Smagorinsky history planes only the
-        // two-step tile fits two workgroups per CU.  LBM_TB_STEPS=2 forces two (A/B, tests).
+        // Steps per launch: the in-place LDS tile kernel with S = 4 (fp32) or 3 (fp64); with the Smagorinsky history planes
+        // the two-step kernel (only it fits two workgroups per CU with 11 planes).  LBM_TB_STEPS=2..5 overrides (A/B, tests).
         const char* ts = std::getenv("LBM_TB_STEPS");
-        c->tb_steps = (p->turb == 0 && !(ts && std::atoi(ts) == 2)) ? 3 : 2;
+        // measured in the full stepper (profiles/r01_logs/perf11.log, perf17.log, perf18.log), 4096^2 MRT: fp32 two steps 140,
+        // three 176, four 207, five 207 GLUPS; fp64 two 75, three 99 (its x rim of V = 2 cells allows no more)
+        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 ? 4 : 3);
+        const bool deep_ok = p->dtype == LBM_F32 && p->nx >= 64 && p->ny_local >= 64;
+        c->tb_steps = p->turb ? 2 : (want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3));
+        c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
         // tile shape of the three-step kernel, A/B in one run (profiles/r01_logs/perf14.log): 14 vectors x 28 rows beats
         // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  LBM_TB3_WIDE=1 selects 30 x 12.
         const char* shp = std::getenv("LBM_TB3_WIDE");
@@ -732,7 +747,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
-    for (int i = 0; i < (c->use_tb ? c->tb_steps + 1 : 2); ++i) {
+    for (int i = 0; i < (c->use_tb ? (c->tb_steps == 2 ? 3 : 4) : 2); ++i) {   // frame passes ping-pong between lat[2], lat[3]
         if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
         // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
         if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));

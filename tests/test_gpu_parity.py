@@ -117,11 +117,17 @@ def test_two_steps_per_launch_is_bit_identical_to_oracle(sem, coll, dtype):
 def test_two_and_three_steps_per_launch_agree(monkeypatch, dtype):
     """The interior advances three steps per launch by default (two with LBM_TB_STEPS=2): same bits either way."""
     o = CavityOracleC(132, 99, 400.0, semantics="mrt_gpu", collision="MRT", dtype=dtype).step(47)
-    for steps in ("2", "3"):
+    for steps in ("2", "3", "4", "5"):   # four, five: fp32 only (fp64 silently stays at three)
         monkeypatch.setenv("LBM_TB_STEPS", steps)
         with CavitySolver(132, 99, 400.0, RT="MRT", dtype=dtype, kernel="tb") as s:
             s.step(47)
             same(s, o, f"LBM_TB_STEPS={steps}")
+    monkeypatch.setenv("LBM_TB_STEPS", "4")
+    for sem, coll in (("mrt_py", "SRT"), ("mrt_gpu", "TRT")):
+        o = CavityOracleC(260, 71, 400.0, semantics=sem, collision=coll, dtype=dtype).step(33)
+        with CavitySolver(260, 71, 400.0, RT=coll, semantics=sem, dtype=dtype, kernel="tb") as s:
+            s.step(33)
+            same(s, o, f"four steps {sem} {coll}")
 
 
 def test_seeded_random_configurations_against_oracle():
