@@ -533,12 +533,19 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
 // their own slot; the region that is still valid shrinks by one cell per step (the V-wide rim in
 // x allows up to V + 1 steps).  Threads outside the valid region compute garbage that nobody uses.
 // ------------------------------------------------------------------------------------------
+// LDS holds only the six directions that cross rows (k = 2, 4, 5, 6, 7, 8); the three that stay in the row are taken
+// from the thread's own registers (k = 0) and from the neighbouring lanes' registers by a wave shuffle (k = 1, 3: the row of
+// PVC vector cells sits in PVC consecutive lanes).  Two thirds of the LDS footprint -> three workgroups per CU.
+constexpr int TB_LDS_PLANES = 6;
+__host__ __device__ constexpr int lds_slot(int k) { return k == 2 ? 0 : k == 4 ? 1 : k - 3; }   // 5,6,7,8 -> 2,3,4,5
+
 template <typename R, int COLL, int V, int TX, int TY, int S>
 __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
                                                     const Relax<R>& w, R* __restrict__ lds, int tx0, int ty0, int xe, int ye) {
     typedef typename VecT<R, V>::type T;
     constexpr int PW = TX + 2 * V, PH = TY + 2 * (S - 1), PVC = PW / V;
     static_assert(S - 1 <= V, "the x rim is only V cells wide");
+    static_assert(64 % PVC == 0, "a row of vector cells must not straddle two waves");
     const int r = threadIdx.x / PVC, vc = threadIdx.x % PVC;
     const int x0 = tx0 - V + vc * V, y = ty0 - (S - 1) + r;
     T in[Q], outv[Q], hq, hr;
@@ -553,14 +560,25 @@ __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R
     for (int s = 2; s <= S; ++s) {
         if (inside) {
 #pragma unroll
-            for (int k = 0; k < Q; ++k) *reinterpret_cast<T*>(lds + ((k * PH + r) * PW + vc * V)) = outv[k];
+            for (int k = 0; k < Q; ++k)
+                if (cyk(k) != 0) *reinterpret_cast<T*>(lds + ((lds_slot(k) * PH + r) * PW + vc * V)) = outv[k];
         }
+        // the in-row directions never leave the registers: east-moving values come from the left neighbour's last
+        // element, west-moving ones from the right neighbour's first (garbage at the two rim columns, which is fine)
+        const R from_left = __shfl_up(outv[1][V - 1], 1);
+        const R from_right = __shfl_down(outv[3][0], 1);
         __syncthreads();
         const bool act = r >= s - 1 && r < PH - (s - 1);
         if (act) {
+            in[0] = outv[0];
+            in[1][0] = from_left;
+            in[3][V - 1] = from_right;
+#pragma unroll
+            for (int c = 1; c < V; ++c) { in[1][c] = outv[1][c - 1]; in[3][c - 1] = outv[3][c]; }
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
-                const R* p = lds + ((k * PH + (r + cyk(k))) * PW + vc * V);
+                if (cyk(k) == 0) continue;
+                const R* p = lds + ((lds_slot(k) * PH + (r + cyk(k))) * PW + vc * V);
                 const T own = *reinterpret_cast<const T*>(p);
                 if (cxk(k) == 0) {
                     in[k] = own;

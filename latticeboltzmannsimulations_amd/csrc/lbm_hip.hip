@@ -84,7 +84,7 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
     update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
-// S = 3 or 4 steps per launch: region of 512 vector cells = one per thread, 72 KiB of LDS.  WIDE: region 32 vectors x 16 rows;
+// S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS (three workgroups per CU).  WIDE: region 32 vectors x 16 rows;
 // otherwise 16 vectors x 32 rows (less rim work, shorter row segments).  The tile is the region minus the rim: V cells
 // left and right, S - 1 rows above and below.  F = frame width (4; 8 for S = 4 in fp32).
 template <typename R, int COLL, int S, bool WIDE>
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(512) void k_stepS_deep(const R* __restrict__ src, R
                                                     int F, int xe, int ye, int ntx, int ntiles) {
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
     constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
-    __shared__ __align__(16) R lds_raw[Q * PH * PW + 2 * V];   // one vector of slack at each end: rim columns read one
-    int b = blockIdx.x;                                         // element past their row
+    __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
+    int b = blockIdx.x;                                                     // read one element past their row
     const int per = ntiles >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
     update_tile_inplace<R, COLL, V, TX, TY, S>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
