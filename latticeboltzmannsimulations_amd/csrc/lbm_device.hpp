@@ -104,11 +104,12 @@ __device__ __forceinline__ void macros(const R (&f)[Q], int x, int gy, int X, in
 // +-1, +-2, +-4 entries of M are exact scalings: value-identical to the dense products.
 template <typename T, int COLL>
 __device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q],
-                                        const Relax<typename ScalarOf<T>::type>& w, T (&out)[Q]) {
-    typedef typename ScalarOf<T>::type R;   // constants and relaxation rates are scalars
+                                        const Relax<typename ScalarOf<T>::type>& w, T w_nu, T (&out)[Q]) {
+    // w_nu: the viscous rate of each cell (w.w_nu, or the Smagorinsky value); the other rates are lattice-wide scalars
+    typedef typename ScalarOf<T>::type R;
     if (COLL == C_SRT) {
 #pragma unroll
-        for (int k = 0; k < Q; ++k) out[k] = f[k] - w.w_nu * (f[k] - feq[k]);
+        for (int k = 0; k < Q; ++k) out[k] = f[k] - w_nu * (f[k] - feq[k]);
     } else if (COLL == C_TRT) {
         T fp[Q], fm[Q], ep[Q], em[Q];
         constexpr int pa[4] = {2, 5, 6, 1}, pb[4] = {4, 7, 8, 3};
@@ -122,7 +123,7 @@ __device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q
         }
         fp[0] = f[0]; fm[0] = T{}; ep[0] = feq[0]; em[0] = T{};
 #pragma unroll
-        for (int k = 0; k < Q; ++k) out[k] = (f[k] - w.w_nu * (fp[k] - ep[k])) - w.w_m * (fm[k] - em[k]);
+        for (int k = 0; k < Q; ++k) out[k] = (f[k] - w_nu * (fp[k] - ep[k])) - w.w_m * (fm[k] - em[k]);
     } else {
         T m[Q], meq[Q];
         // rows of M_GS (MRT.py:163-173), left-to-right sums
@@ -145,9 +146,11 @@ __device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q
         meq[6] = -jy + (R)3.0 * ((jy * jy) * jy);
         meq[7] = jx * jx - jy * jy;
         meq[8] = jx * jy;
-        const R wv[Q] = {(R)0, w.w_e, w.w_eps, (R)0, w.w_q, (R)0, w.w_q, w.w_nu, w.w_nu};
+        const R wv[7] = {(R)0, w.w_e, w.w_eps, (R)0, w.w_q, (R)0, w.w_q};
 #pragma unroll
-        for (int k = 0; k < Q; ++k) m[k] = m[k] - wv[k] * (m[k] - meq[k]);
+        for (int k = 0; k < 7; ++k) m[k] = m[k] - wv[k] * (m[k] - meq[k]);
+        m[7] = m[7] - w_nu * (m[7] - meq[7]);
+        m[8] = m[8] - w_nu * (m[8] - meq[8]);
         // rows of M_GS_INV (MRT.py:175-183)
         const R a9 = (R)(1.0 / 9), a36 = (R)(1.0 / 36), a18 = (R)(1.0 / 18), a6 = (R)(1.0 / 6),
                 a12 = (R)(1.0 / 12), a4 = (R)(1.0 / 4);
@@ -170,20 +173,24 @@ __device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q
 constexpr int K_QEQ = Q;      // plane index of  -feq8 + (feq7 + (-feq6 + feq5))  of the previous step
 constexpr int K_RHO = Q + 1;  // plane index of the previous step's density (after the lid override)
 
-template <typename R>
-__device__ __forceinline__ R diag_flux(const R (&f)[Q]) {   // product = cx cy f_k + product, k = 0..8
+template <typename T>
+__device__ __forceinline__ T diag_flux(const T (&f)[Q]) {   // product = cx cy f_k + product, k = 0..8
     return -f[8] + (f[7] + (-f[6] + f[5]));
 }
 __device__ __forceinline__ float real_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double real_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ f32x2 real_sqrt(f32x2 x) { return f32x2{sqrtf(x.x), sqrtf(x.y)}; }
 __device__ __forceinline__ float real_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double real_abs(double x) { return fabs(x); }
+__device__ __forceinline__ f32x2 real_abs(f32x2 x) { return f32x2{fabsf(x.x), fabsf(x.y)}; }
 
-template <typename R>
-__device__ __forceinline__ R smagorinsky_omega(const R (&f)[Q], R qeq_prev, R rho_prev, R omega) {
+// T: scalar real or f32x2; the result is the per-cell relaxation rate (a T, not a scalar)
+template <typename T>
+__device__ __forceinline__ T smagorinsky_omega(const T (&f)[Q], T qeq_prev, T rho_prev, typename ScalarOf<T>::type omega) {
+    typedef typename ScalarOf<T>::type R;
     const R tau0 = (R)1.0 / omega;
-    const R q = diag_flux<R>(f) - qeq_prev;
-    const R tau = (R)0.5 * (tau0 + real_sqrt(tau0 * tau0 + (((R)(18 * 1.4142) * (R)0.025) * real_abs(q)) / rho_prev));
+    const T q = diag_flux<T>(f) - qeq_prev;
+    const T tau = (R)0.5 * (tau0 + real_sqrt(tau0 * tau0 + (((R)(18 * 1.4142) * (R)0.025) * real_abs(q)) / rho_prev));
     return (R)1.0 / tau;
 }
 
@@ -291,11 +298,12 @@ __device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __rest
     }
     R rho, ux, uy, fe[Q], out[Q];
     const long long me = geo.at(x, y);
-    Relax<R> w = w0;
-    if (TURB) w.w_nu = smagorinsky_omega<R>(g, src[K_QEQ * geo.plane + me], src[K_RHO * geo.plane + me], w0.w_nu);
+    const Relax<R>& w = w0;
+    R w_nu = w0.w_nu;
+    if (TURB) w_nu = smagorinsky_omega<R>(g, src[K_QEQ * geo.plane + me], src[K_RHO * geo.plane + me], w0.w_nu);
     macros<R>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
     equ<R>(rho, ux, uy, fe);
-    collide<R, COLL>(g, rho, fe, w, out);
+    collide<R, COLL>(g, rho, fe, w, w_nu, out);
     if (TURB) {
         dst[K_QEQ * geo.plane + me] = diag_flux<R>(fe);
         dst[K_RHO * geo.plane + me] = rho;
@@ -375,8 +383,8 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
             if (left) { g[1] = (R)0 + g[3]; g[5] = (R)0 + g[7]; g[8] = (R)0 + g[6]; }
             if (right) { g[3] = (R)0 + g[1]; g[6] = (R)0 + g[8]; g[7] = (R)0 + g[5]; }
         }
-        Relax<R> w = w0;
-        if (TURB) w.w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
+        R w_nu = w0.w_nu;
+        if (TURB) w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
         R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
         if (COLL != C_MRT || TURB) {   // the plain MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
             R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
@@ -384,7 +392,7 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
             if (left || right) { ux = (R)0; uy = (R)0; }
             equ<R>(rho, ux, uy, fe);
         }
-        collide<R, COLL>(g, rho, fe, w, out);
+        collide<R, COLL>(g, rho, fe, w0, w_nu, out);
 #pragma unroll
         for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
         if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
@@ -416,24 +424,31 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
                                             typename VecT<R, V>::type (&outv)[Q],
                                             typename VecT<R, V>::type& hq, typename VecT<R, V>::type& hr) {
     // hq, hr: Smagorinsky history of the cells (in: previous step, out: this step); untouched unless TURB
-    if constexpr (sizeof(R) == 4 && V == 4 && !TURB) {
+    if constexpr (sizeof(R) == 4 && V == 4) {
         // fp32: two cells per operation (packed math), same lane-wise IEEE operations as the scalar form below
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             f32x2 g[Q], out[Q], fe[Q];
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = p == 0 ? in[k].xy : in[k].zw;
+            f32x2 w_nu = (f32x2)(w0.w_nu);
+            if (TURB) w_nu = smagorinsky_omega<f32x2>(g, p == 0 ? hq.xy : hq.zw, p == 0 ? hr.xy : hr.zw, w0.w_nu);
             const f32x2 rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
-            if (COLL != C_MRT) {
+            if (COLL != C_MRT || TURB) {
                 const f32x2 ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
                 const f32x2 uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
                 equ<f32x2>(rho, ux, uy, fe);
             }
-            collide<f32x2, COLL>(g, rho, fe, w0, out);
+            collide<f32x2, COLL>(g, rho, fe, w0, w_nu, out);
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
                 if (p == 0) outv[k].xy = out[k];
                 else outv[k].zw = out[k];
+            }
+            if (TURB) {
+                const f32x2 q2 = diag_flux<f32x2>(fe);
+                if (p == 0) { hq.xy = q2; hr.xy = rho; }
+                else { hq.zw = q2; hr.zw = rho; }
             }
         }
     } else {
@@ -442,15 +457,15 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
             R g[Q], out[Q], fe[Q];
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = in[k][c];
-            Relax<R> w = w0;
-            if (TURB) w.w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
+            R w_nu = w0.w_nu;
+            if (TURB) w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
             const R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
             if (COLL != C_MRT || TURB) {
                 const R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
                 const R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
                 equ<R>(rho, ux, uy, fe);
             }
-            collide<R, COLL>(g, rho, fe, w, out);
+            collide<R, COLL>(g, rho, fe, w0, w_nu, out);
 #pragma unroll
             for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
             if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
@@ -539,7 +554,7 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
 constexpr int TB_LDS_PLANES = 6;
 __host__ __device__ constexpr int lds_slot(int k) { return k == 2 ? 0 : k == 4 ? 1 : k - 3; }   // 5,6,7,8 -> 2,3,4,5
 
-template <typename R, int COLL, int V, int TX, int TY, int S>
+template <typename R, int COLL, int V, int TX, int TY, int S, bool TURB>
 __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
                                                     const Relax<R>& w, R* __restrict__ lds, int tx0, int ty0, int xe, int ye) {
     typedef typename VecT<R, V>::type T;
@@ -554,7 +569,11 @@ __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R
 #pragma unroll
         for (int k = 0; k < Q; ++k)
             in[k] = vload<R, V, false>(src + k * geo.plane + geo.at(x0 - cxk(k), y + cyk(k)), cxk(k) == 0);
-        collide_vec<R, COLL, V, false>(in, w, outv, hq, hr);
+        if (TURB) {   // the Smagorinsky history is cell-local: it stays in this thread's registers for all S steps
+            hq = vload<R, V, false>(src + K_QEQ * geo.plane + geo.at(x0, y), true);
+            hr = vload<R, V, false>(src + K_RHO * geo.plane + geo.at(x0, y), true);
+        }
+        collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);
     }
 #pragma unroll
     for (int s = 2; s <= S; ++s) {
@@ -595,12 +614,16 @@ __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R
         }
         if (s < S) __syncthreads();   // everyone has read before anyone overwrites in place
         // (the rim columns are needed by the next step but not after the last one)
-        if (act && (s < S || (vc >= 1 && vc < PVC - 1))) collide_vec<R, COLL, V, false>(in, w, outv, hq, hr);
+        if (act && (s < S || (vc >= 1 && vc < PVC - 1))) collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);
     }
     if (r >= S - 1 && r < PH - (S - 1) && vc >= 1 && vc < PVC - 1 && x0 < xe && y < ye) {
         const long long me = geo.at(x0, y);
 #pragma unroll
         for (int k = 0; k < Q; ++k) vstore<R, V, false>(dst + k * geo.plane + me, outv[k]);
+        if (TURB) {
+            vstore<R, V, false>(dst + K_QEQ * geo.plane + me, hq);
+            vstore<R, V, false>(dst + K_RHO * geo.plane + me, hr);
+        }
     }
 }
 

@@ -84,11 +84,13 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
     update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
-// S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS (three workgroups per CU).  WIDE: region 32 vectors x 16 rows;
+// S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS.  The
+// occupancy floor of 4 waves per SIMD (<= 128 VGPRs) keeps two workgroups on a CU: the MRT / TRT + Smagorinsky variants would
+// otherwise take 132 and run one (perf22.log vs perf23.log: fp32 MRT turb 96 -> 115 GLUPS).  WIDE: region 32 vectors x 16 rows;
 // otherwise 16 vectors x 32 rows (less rim work, shorter row segments).  The tile is the region minus the rim: V cells
 // left and right, S - 1 rows above and below.  F = frame width (4; 8 for S = 4 in fp32).
-template <typename R, int COLL, int S, bool WIDE>
-__global__ __launch_bounds__(512) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+template <typename R, int COLL, int S, bool WIDE, bool TURB>
+__global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                     int F, int xe, int ye, int ntx, int ntiles) {
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
     constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(512) void k_stepS_deep(const R* __restrict__ src, R
     int b = blockIdx.x;                                                     // read one element past their row
     const int per = ntiles >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
-    update_tile_inplace<R, COLL, V, TX, TY, S>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
+    update_tile_inplace<R, COLL, V, TX, TY, S, TURB>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
 }
 
 // One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
@@ -219,7 +221,7 @@ struct lbm_ctx {
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
-    int tb_steps = 2;           // ... or three (without the Smagorinsky closure)
+    int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel)
     bool tb3_wide = false;      // tile shape of the three/four-step kernel: region 32 vectors x 16 rows instead of 16 x 32
     int tb_f = TB_F;            // frame width
     std::string err;
@@ -379,7 +381,7 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
                 constexpr bool WIDE = decltype(wide)::value;
                 constexpr int PVC = WIDE ? 32 : 16, TX = (PVC - 2) * V, TY = 512 / PVC - 2 * (S - 1);
                 const int ntx = (xe - F + TX - 1) / TX, nty = (ye - F + TY - 1) / TY;
-                hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, S, WIDE>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
+                hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, S, WIDE, VT::TURB>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
                                    (R*)c->lat[to], c->geo, relax_of<R>(c->p), F, xe, ye, ntx, ntx * nty);
             };
             if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
@@ -718,14 +720,17 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // a double step do not pay
         const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
-        // Steps per launch: the in-place LDS tile kernel with S = 4 (fp32) or 3 (fp64); with the Smagorinsky history planes
-        // the two-step kernel (only it fits two workgroups per CU with 11 planes).  LBM_TB_STEPS=2..5 overrides (A/B, tests).
+        // Steps per launch: the in-place LDS tile kernel with S = 4 (fp32) or 3 (fp64), also with the Smagorinsky closure (its
+        // history is cell-local and stays in registers).  LBM_TB_STEPS=2..5 overrides (A/B, tests; 2 = the two-phase kernel).
         const char* ts = std::getenv("LBM_TB_STEPS");
         // measured in the full stepper (profiles/r01_logs/perf11.log, perf17.log, perf18.log), 4096^2 MRT: fp32 two steps 140,
         // three 176, four 207, five 207 GLUPS; fp64 two 75, three 99 (its x rim of V = 2 cells allows no more)
-        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 ? 4 : 3);
+        // with the closure (perf23.log, 4096^2 fp32, S = 2 / 3 / 4): SRT 108 / 150 / 162, TRT 110 / 145 / 124 (S = 4 spills
+        // under the 128-register occupancy floor), MRT 109 / 111 / 115; fp64 SRT 57 / 81 / 83, MRT 61 / 72 / 73
+        const bool trt_turb = p->turb && p->collision == LBM_TRT;
+        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 && !trt_turb ? 4 : 3);
         const bool deep_ok = p->dtype == LBM_F32 && p->nx >= 64 && p->ny_local >= 64;
-        c->tb_steps = p->turb ? 2 : (want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3));
+        c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
         c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
         // tile shape of the three-step kernel, A/B in one run (profiles/r01_logs/perf14.log): 14 vectors x 28 rows beats
         // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  LBM_TB3_WIDE=1 selects 30 x 12.
