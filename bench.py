@@ -75,8 +75,37 @@ def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=15.0):
                       f"OpenMP, {threads} threads), {dt:.1f} s"}
 
 
+def cpu_table():
+    """SURVEY 8(d) CPU baselines beside the GPU number: the NumPy restatement (1 thread) and the C restatement at 1, 4 (the
+    thread count hard-coded in functions.pyx:69) and all granted cores, MRT.py semantics / SRT / fp64 (what MRT.py runs) and
+    MRT_GPU.py semantics / MRT.  Part of the cpu_baseline leg: oracle code timed as a baseline, nothing shipped."""
+    from oracle import lbm_ref
+    from oracle.lbm_numpy import CavityOracle
+    rows = []
+    for n, steps in ((128, 200), (1024, 10)):
+        o = CavityOracle(n, n, 1000.0, semantics="mrt_py", collision="SRT", dtype=np.float64)
+        o.step(2)
+        t = time.perf_counter(); o.step(steps); dt = time.perf_counter() - t
+        rows.append({"impl": "oracle/lbm_numpy.py", "threads": 1, "lattice": n, "case": "mrt_py SRT f64", "MLUPS": round(n * n * steps / dt / 1e6, 2)})
+        print(json.dumps(rows[-1]), flush=True)
+    allc = max(1, min(lbm_ref.max_threads(), host_cores()))
+    for threads in sorted({1, 4, allc}):
+        lbm_ref.set_threads(threads)
+        for n, steps in ((128, 2000), (1024, 60), (4096, 6)):
+            for sem, coll, dt_ in (("mrt_py", "SRT", np.float64), ("mrt_gpu", "MRT", np.float64), ("mrt_gpu", "MRT", np.float32)):
+                o = lbm_ref.CavityOracleC(n, n, 1000.0, semantics=sem, collision=coll, dtype=np.dtype(dt_))
+                o.step(2)
+                t = time.perf_counter(); o.step(steps); dt = time.perf_counter() - t
+                rows.append({"impl": "oracle/lbm_ref.c", "threads": threads, "lattice": n, "case": f"{sem} {coll} {np.dtype(dt_).name}",
+                             "MLUPS": round(n * n * steps / dt / 1e6, 2)})
+                print(json.dumps(rows[-1]), flush=True)
+    lbm_ref.set_threads(1)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-table", action="store_true", help="time the CPU restatements only (SURVEY 8d table) and exit")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=60)
@@ -86,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short side measurements reported under 'other'")
     a = ap.parse_args()
+    if a.cpu_table:
+        cpu_table()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

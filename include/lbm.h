@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 1
+#define LBM_ABI_VERSION 2
 
 typedef enum lbm_status {
     LBM_OK = 0,
@@ -60,6 +60,11 @@ typedef struct lbm_params {
     int32_t turb;        /* 0 | 1: Smagorinsky closure of MRT_GPU.py:368-387 (MRT_GPU semantics only) */
     int32_t device;      /* HIP device ordinal (reference: cuda.Device(0), MRT_GPU.py:29) */
     int32_t layout;      /* LBM_LAYOUT_* (device-side only; host arrays are unaffected) */
+    int32_t batch;       /* 0 / 1: one lattice.  B > 1: B independent cavities of the same size and scheme advanced by
+                            the same launches, each with its own relaxation rates -- the Reynolds sweep that
+                            MRT_GPU_datagen.py:55-57,879-902 runs one lattice after the other.  Host arrays gain a
+                            leading [B] axis.  Not combinable with slabs. */
+    int32_t reserved;    /* 0 */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */
     double omega;        /* = omegap = omega_nu, MRT_GPU.py:65 */
     double omegam;       /* TRT, MRT_GPU.py:80 */
@@ -89,8 +94,14 @@ const char* lbm_last_error(const lbm_ctx* c);
 int lbm_init_equilibrium(lbm_ctx* c);
 /* replaces: per-plane transpose + cuda.memcpy_htod(fin_g, fin) (MRT_GPU.py:283-289,323).
  * fin_host is the WHOLE-lattice array fin[9][nx][ny]; the context reads its own rows
- * y0 .. y0+ny_local-1.  host_dtype is LBM_F32 or LBM_F64 (converted if it differs). */
+ * y0 .. y0+ny_local-1.  host_dtype is LBM_F32 or LBM_F64 (converted if it differs).
+ * With batch = B > 1: fin[B][9][nx][ny]. */
 int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype);
+
+/* replaces: the per-Reynolds-number recompilation of the kernel source (MRT_GPU_datagen.py:57,63-93 -> 701-703):
+ * sets the relaxation rates of lattice `index` of the batch (0 for a single lattice) for all later steps. */
+int lbm_set_relaxation(lbm_ctx* c, int index, double omega, double omegam, double omega_e, double omega_eps,
+                       double omega_q);
 
 /* --- time loop --------------------------------------------------------------------- */
 /* replaces: funRT(...); funBC(...) launched from the Python loop (MRT_GPU.py:707-732).
@@ -112,7 +123,8 @@ long long lbm_steps_done(const lbm_ctx* c);
  * receive the macroscopic fields computed in the LAST iteration (one-step lag of the
  * reference: u_g/rho_g are written inside funRT before collide/stream); fin_host
  * [9][nx][ny] receives the current populations (post stream + wall rules).  Any pointer
- * may be NULL.  Whole-lattice arrays; only this context's rows are written. */
+ * may be NULL.  Whole-lattice arrays; only this context's rows are written.
+ * With batch = B > 1: u_host[B][2][nx][ny], rho_host[B][nx][ny], fin_host[B][9][nx][ny]. */
 int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int host_dtype);
 
 /* --- slab decomposition, externally driven exchange ---------------------------------- */

@@ -29,6 +29,7 @@ class lbm_params(ctypes.Structure):
                 ("y0", ctypes.c_int32), ("ny_local", ctypes.c_int32), ("dtype", ctypes.c_int32),
                 ("collision", ctypes.c_int32), ("semantics", ctypes.c_int32), ("kernel", ctypes.c_int32),
                 ("turb", ctypes.c_int32), ("device", ctypes.c_int32), ("layout", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("uLB", ctypes.c_double), ("omega", ctypes.c_double), ("omegam", ctypes.c_double),
                 ("omega_e", ctypes.c_double), ("omega_eps", ctypes.c_double), ("omega_q", ctypes.c_double)]
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "lbm_last_error": (ctypes.c_char_p, [_vp]),
     "lbm_init_equilibrium": (_i, [_vp]),
     "lbm_set_state": (_i, [_vp, _vp, _i]),
+    "lbm_set_relaxation": (_i, [_vp, _i, _d, _d, _d, _d, _d]),
     "lbm_step": (_i, [_vp, _i]),
     "lbm_sync": (_i, [_vp]),
     "lbm_time_steps": (_i, [_vp, _i, ctypes.POINTER(_d)]),
@@ -114,7 +116,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if an exported symbol is missing
             f.restype, f.argtypes = res, args
-        if L.lbm_abi_version() != 1:
+        if L.lbm_abi_version() != 2:
             raise RuntimeError("liblbm_hip.so ABI version mismatch")
         _lib = L
     return _lib

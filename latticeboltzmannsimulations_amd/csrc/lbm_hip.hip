@@ -22,13 +22,28 @@ using namespace lbm;
 // ------------------------------------------------------------------------------------
 constexpr int BLK = 256;
 
+// A batch of independent lattices advanced by one launch (lbm_params.batch): lattice z of the batch lives `stride` elements
+// further on in every device buffer and has its own relaxation rates w[z].  w == nullptr: a single lattice, rates by value.
+template <typename R>
+struct Batch {
+    long long stride;
+    const Relax<R>* w;
+};
+#define LBM_BATCH_SELECT(z)            \
+    if (bt.w) {                        \
+        src += (z) * bt.stride;        \
+        dst += (z) * bt.stride;        \
+        w = bt.w[(z)];                 \
+    }
+
 // Generic fused step: one thread per cell, rows y = row0 + blockIdx.y * row_stride.
 template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src, R* __restrict__ dst, Geo geo,
-                                                      Relax<R> w, int raw, int row0, int row_stride) {
+                                                      Relax<R> w, Batch<R> bt, int raw, int row0, int row_stride) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = row0 + blockIdx.y * row_stride;
     if (x >= geo.nx) return;
+    LBM_BATCH_SELECT(blockIdx.z)
     update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, raw, x, y);
 }
 
@@ -41,7 +56,8 @@ __global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src,
 #endif
 template <typename R, int COLL, int V, bool NT, bool TURB>
 __global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
-                                                  int raw, int row0, int row_stride, int nxb, int nblocks) {
+                                                  Batch<R> bt, int raw, int row0, int row_stride, int nxb, int nblocks) {
+    LBM_BATCH_SELECT(blockIdx.y)
     int b = blockIdx.x;
     const int per = nblocks >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
@@ -75,7 +91,8 @@ template <bool TURB> constexpr int tb_txv() { return TURB ? 30 : 62; }
 
 template <typename R, int COLL, bool TURB>
 __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
-                                                      int xe, int ye, int ntx, int ntiles) {
+                                                      Batch<R> bt, int xe, int ye, int ntx, int ntiles) {
+    LBM_BATCH_SELECT(blockIdx.y)
     constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<TURB>() * V, TY = tb_ty<TURB>();
     __shared__ __align__(16) R lds[(TURB ? Q + 2 : Q) * (TY + 2) * (TX + 2 * V)];
     int b = blockIdx.x;
@@ -91,7 +108,8 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
 // left and right, S - 1 rows above and below.  F = frame width (4; 8 for S = 4 in fp32).
 template <typename R, int COLL, int S, bool WIDE, bool TURB>
 __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
-                                                    int F, int xe, int ye, int ntx, int ntiles) {
+                                                    Batch<R> bt, int F, int xe, int ye, int ntx, int ntiles) {
+    LBM_BATCH_SELECT(blockIdx.y)
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
     constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
     __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
@@ -104,7 +122,8 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
 // One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
 // [nx-W, nx) of the rows in between.  One thread per cell, complete wall / kept-slot logic.
 template <typename R, int COLL, int SEM, bool TURB>
-__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int W) {
+__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, Batch<R> bt, int W) {
+    LBM_BATCH_SELECT(blockIdx.y)
     const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long nrow = 2LL * W * geo.nx, ncol = 2LL * W * (geo.ny - 2 * W);
     int x, y;
@@ -125,10 +144,11 @@ __global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R
 
 // init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
 template <typename R>
-__global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB, int turb) {
+__global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB, int turb, long long bstride) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= geo.nx) return;
+    lat += blockIdx.z * bstride;
     R fe[Q];
     equ<R>((R)1, (geo.y0 + y) == 0 ? uLB : (R)0, (R)0, fe);
 #pragma unroll
@@ -141,11 +161,13 @@ __global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uL
 
 // staging (reference host layout, [9][nx][ny_local], y fastest) -> raw lattice
 template <typename R>
-__global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* __restrict__ lat, Geo geo, R uLB, int turb) {
+__global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* __restrict__ lat, Geo geo, R uLB, int turb, long long bstride) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= geo.nx) return;
     const long long n = (long long)geo.nx * geo.ny;
+    lat += blockIdx.z * bstride;
+    stage += blockIdx.z * (Q * n);
     R g[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
@@ -164,13 +186,15 @@ __global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* 
 // lattice -> staging: current populations (post stream + wall rules) in host layout
 template <typename R, int SEM>
 __global__ __launch_bounds__(BLK) void k_export_fin(const R* __restrict__ src, Geo geo, int raw, R uLB,
-                                                    R* __restrict__ stage) {
+                                                    R* __restrict__ stage, long long bstride) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= geo.nx) return;
+    const long long n = (long long)geo.nx * geo.ny;
+    src += blockIdx.z * bstride;
+    stage += blockIdx.z * (Q * n);
     R g[Q];
     gather<R, SEM>(src, geo, raw, uLB, x, y, g);
-    const long long n = (long long)geo.nx * geo.ny;
 #pragma unroll
     for (int k = 0; k < Q; ++k) stage[k * n + (long long)x * geo.ny + y] = g[k];
 }
@@ -179,14 +203,16 @@ __global__ __launch_bounds__(BLK) void k_export_fin(const R* __restrict__ src, G
 // from `src`; stage = [ux | uy | rho], each [nx][ny_local]
 template <typename R, int SEM>
 __global__ __launch_bounds__(BLK) void k_export_macro(const R* __restrict__ src, Geo geo, int raw, R uLB,
-                                                      R* __restrict__ stage) {
+                                                      R* __restrict__ stage, long long bstride) {
     const int x = blockIdx.x * BLK + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= geo.nx) return;
+    const long long n = (long long)geo.nx * geo.ny;
+    src += blockIdx.z * bstride;
+    stage += blockIdx.z * (3 * n);
     R g[Q], rho, ux, uy;
     gather<R, SEM>(src, geo, raw, uLB, x, y, g);
     macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
-    const long long n = (long long)geo.nx * geo.ny;
     const long long o = (long long)x * geo.ny + y;
     stage[o] = ux;
     stage[n + o] = uy;
@@ -224,6 +250,9 @@ struct lbm_ctx {
     int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel)
     bool tb3_wide = false;      // tile shape of the three/four-step kernel: region 32 vectors x 16 rows instead of 16 x 32
     int tb_f = TB_F;            // frame width
+    int batch = 1;              // independent lattices per buffer (lbm_params.batch)
+    long long bstride = 0;      // elements from one lattice of the batch to the next
+    void* relax_dev = nullptr;  // batch > 1: Relax<real>[batch] on the device
     std::string err;
 };
 
@@ -298,7 +327,12 @@ Relax<R> relax_of(const lbm_params& p) {
     return w;
 }
 
-dim3 grid_rows(const lbm_ctx* c, int nrows) { return dim3((c->geo.nx + BLK - 1) / BLK, nrows, 1); }
+template <typename R>
+Batch<R> batch_of(const lbm_ctx* c) {
+    return Batch<R>{c->bstride, c->batch > 1 ? (const Relax<R>*)c->relax_dev : nullptr};
+}
+
+dim3 grid_rows(const lbm_ctx* c, int nrows) { return dim3((c->geo.nx + BLK - 1) / BLK, nrows, c->batch); }
 
 // Run-time parameters -> compile-time kernel variant (real type, collision operator, semantics, Smagorinsky).
 template <typename R_, int COLL_, int SEM_, bool TURB_>
@@ -341,14 +375,14 @@ int launch_rows(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
             constexpr int V = 16 / (int)sizeof(R);
             const int nxb = (c->geo.nx / V + BLK - 1) / BLK, nblocks = nxb * nrows;
             if (c->use_nt)
-                hipLaunchKernelGGL((k_step_vec<R, VT::COLL, V, true, VT::TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
-                                   relax_of<R>(c->p), raw, row0, stride, nxb, nblocks);
+                hipLaunchKernelGGL((k_step_vec<R, VT::COLL, V, true, VT::TURB>), dim3(nblocks, c->batch), dim3(BLK), 0, s, src, dst, c->geo,
+                                   relax_of<R>(c->p), batch_of<R>(c), raw, row0, stride, nxb, nblocks);
             else
-                hipLaunchKernelGGL((k_step_vec<R, VT::COLL, V, false, VT::TURB>), dim3(nblocks), dim3(BLK), 0, s, src, dst, c->geo,
-                                   relax_of<R>(c->p), raw, row0, stride, nxb, nblocks);
+                hipLaunchKernelGGL((k_step_vec<R, VT::COLL, V, false, VT::TURB>), dim3(nblocks, c->batch), dim3(BLK), 0, s, src, dst, c->geo,
+                                   relax_of<R>(c->p), batch_of<R>(c), raw, row0, stride, nxb, nblocks);
         } else {
             hipLaunchKernelGGL((k_step_generic<R, VT::COLL, VT::SEM, VT::TURB>), grid_rows(c, nrows), dim3(BLK), 0, s, src, dst,
-                               c->geo, relax_of<R>(c->p), raw, row0, stride);
+                               c->geo, relax_of<R>(c->p), batch_of<R>(c), raw, row0, stride);
         }
     });
     HIP_TRY(c, hipGetLastError());
@@ -361,8 +395,8 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s) {
         using VT = decltype(v);
         using R = typename VT::R;
         const long long cells = 2LL * W * c->geo.nx + 2LL * W * (c->geo.ny - 2 * W);
-        hipLaunchKernelGGL((k_step_frame<R, VT::COLL, VT::SEM, VT::TURB>), dim3((unsigned)((cells + BLK - 1) / BLK)), dim3(BLK), 0, s,
-                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), W);
+        hipLaunchKernelGGL((k_step_frame<R, VT::COLL, VT::SEM, VT::TURB>), dim3((unsigned)((cells + BLK - 1) / BLK), c->batch), dim3(BLK), 0, s,
+                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), W);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -381,8 +415,8 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
                 constexpr bool WIDE = decltype(wide)::value;
                 constexpr int PVC = WIDE ? 32 : 16, TX = (PVC - 2) * V, TY = 512 / PVC - 2 * (S - 1);
                 const int ntx = (xe - F + TX - 1) / TX, nty = (ye - F + TY - 1) / TY;
-                hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, S, WIDE, VT::TURB>), dim3(ntx * nty), dim3(512), 0, s, (const R*)c->lat[from],
-                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), F, xe, ye, ntx, ntx * nty);
+                hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, S, WIDE, VT::TURB>), dim3(ntx * nty, c->batch), dim3(512), 0, s, (const R*)c->lat[from],
+                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty);
             };
             if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
                 if (c->tb_steps == 4) {
@@ -402,8 +436,8 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
         }
         constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<VT::TURB>() * V, TY = tb_ty<VT::TURB>();
         const int ntx = (xe - TB_F + TX - 1) / TX, nty = (ye - TB_F + TY - 1) / TY;   // two steps: F = TB_F
-        hipLaunchKernelGGL((k_step2_deep<R, VT::COLL, VT::TURB>), dim3(ntx * nty), dim3(TB_NT), 0, s, (const R*)c->lat[from],
-                           (R*)c->lat[to], c->geo, relax_of<R>(c->p), xe, ye, ntx, ntx * nty);
+        hipLaunchKernelGGL((k_step2_deep<R, VT::COLL, VT::TURB>), dim3(ntx * nty, c->batch), dim3(TB_NT), 0, s, (const R*)c->lat[from],
+                           (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), xe, ye, ntx, ntx * nty);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -632,9 +666,9 @@ int export_fin_t(lbm_ctx* c) {
     const dim3 g = grid_rows(c, c->geo.ny);
     const R* src = (const R*)c->lat[c->cur];
     if (c->p.semantics == LBM_SEM_MRT_PY)
-        hipLaunchKernelGGL((k_export_fin<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[c->cur], (R)c->p.uLB, (R*)c->stage);
+        hipLaunchKernelGGL((k_export_fin<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[c->cur], (R)c->p.uLB, (R*)c->stage, c->bstride);
     else
-        hipLaunchKernelGGL((k_export_fin<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[c->cur], (R)c->p.uLB, (R*)c->stage);
+        hipLaunchKernelGGL((k_export_fin<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[c->cur], (R)c->p.uLB, (R*)c->stage, c->bstride);
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
 }
@@ -647,9 +681,9 @@ int export_macro_t(lbm_ctx* c) {
     const int which = c->nsteps > 0 ? (c->cur ^ 1) : c->cur;
     const R* src = (const R*)c->lat[which];
     if (c->p.semantics == LBM_SEM_MRT_PY)
-        hipLaunchKernelGGL((k_export_macro<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage);
+        hipLaunchKernelGGL((k_export_macro<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage, c->bstride);
     else
-        hipLaunchKernelGGL((k_export_macro<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage);
+        hipLaunchKernelGGL((k_export_macro<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage, c->bstride);
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
 }
@@ -685,6 +719,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return bail("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
     if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_TB) return bail("bad kernel variant");
     if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
+    if (p->batch < 0 || p->batch > 65535 || p->reserved != 0) return bail("batch must be 0 .. 65535 (and reserved 0)");
+    if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return bail("a batch of lattices cannot be slab-decomposed");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return bail(std::string("no HIP device: ") + hipGetErrorString(e));
@@ -708,7 +744,9 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->geo.plane = c->geo.pitch;
         c->geo.row = (long long)nplanes * c->geo.pitch;
     }
-    const size_t bytes = (size_t)nplanes * c->geo.pitch * (p->ny_local + 2) * c->es;
+    c->batch = p->batch > 1 ? p->batch : 1;
+    c->bstride = (long long)nplanes * c->geo.pitch * (p->ny_local + 2);   // lattice z of a batch starts z * bstride elements in
+    const size_t bytes = (size_t)c->bstride * c->batch * c->es;
     {
         const int V = 16 / c->es;
         const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;
@@ -718,7 +756,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
         // measured crossover (profiles/r01_logs/perf4.log): below ~768^2 cells a step is launch-bound and the three launches of
         // a double step do not pay
-        const bool big = (long long)p->nx * p->ny_local >= 768LL * 768LL;
+        const bool big = (long long)p->nx * p->ny_local * c->batch >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
         // Steps per launch: the in-place LDS tile kernel with S = 4 (fp32) or 3 (fp64), also with the Smagorinsky closure (its
         // history is cell-local and stays in registers).  LBM_TB_STEPS=2..5 overrides (A/B, tests; 2 = the two-phase kernel).
@@ -757,6 +795,12 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
         if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
     }
+    if (c->batch > 1) {   // every lattice starts with the rates of lbm_params; lbm_set_relaxation() changes them one by one
+        const size_t rb = c->es == 4 ? sizeof(Relax<float>) : sizeof(Relax<double>);
+        if ((e = hipMalloc(&c->relax_dev, rb * c->batch)) != hipSuccess) return cleanup(std::string("hipMalloc(relaxation): ") + hipGetErrorString(e));
+        for (int i = 0; i < c->batch; ++i)
+            if (lbm_set_relaxation(c, i, p->omega, p->omegam, p->omega_e, p->omega_eps, p->omega_q) != LBM_OK) return cleanup(c->err);
+    }
     if (lbm_init_equilibrium(c) != LBM_OK) return cleanup(c->err);
     return c;
 }
@@ -770,6 +814,7 @@ void lbm_destroy(lbm_ctx* c) {
     for (int i = 0; i < 4; ++i)
         if (c->lat[i]) (void)hipFree(c->lat[i]);
     if (c->stage) (void)hipFree(c->stage);
+    if (c->relax_dev) (void)hipFree(c->relax_dev);
     if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);
     if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
     if (c->ev_int) (void)hipEventDestroy(c->ev_int);
@@ -790,9 +835,9 @@ int lbm_init_equilibrium(lbm_ctx* c) {
     c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
-        hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb);
+        hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
     else
-        hipLaunchKernelGGL((k_init<double>), g, dim3(BLK), 0, c->s_compute, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb);
+        hipLaunchKernelGGL((k_init<double>), g, dim3(BLK), 0, c->s_compute, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb, c->bstride);
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
 }
@@ -802,17 +847,40 @@ int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
     HIP_TRY(c, hipSetDevice(c->p.device));
     int rc = sync_all(c);
     if (rc) return rc;
-    rc = ensure_stage(c, (size_t)12 * c->geo.nx * c->geo.ny * c->es);
+    rc = ensure_stage(c, (size_t)12 * c->geo.nx * c->geo.ny * c->es * c->batch);
     if (rc) return rc;
-    rc = host_to_stage(c, fin_host, host_dtype, Q);
+    rc = host_to_stage(c, fin_host, host_dtype, Q * c->batch);   // [B][9][nx][ny] is B * 9 planes
     if (rc) return rc;
     c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
-        hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb);
+        hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
     else
-        hipLaunchKernelGGL((k_import<double>), g, dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb);
+        hipLaunchKernelGGL((k_import<double>), g, dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb, c->bstride);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return LBM_OK;
+}
+
+int lbm_set_relaxation(lbm_ctx* c, int index, double omega, double omegam, double omega_e, double omega_eps, double omega_q) {
+    if (!c || index < 0 || index >= c->batch) return fail(c, LBM_ERR_INVALID, "lbm_set_relaxation: index out of range");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    lbm_params q = c->p;
+    q.omega = omega; q.omegam = omegam; q.omega_e = omega_e; q.omega_eps = omega_eps; q.omega_q = omega_q;
+    if (c->batch == 1) {   // rates travel by value with every launch
+        c->p = q;
+        return LBM_OK;
+    }
+    // ordered behind the steps already enqueued: the copy goes through the compute stream (pageable source, so the call
+    // returns only after the runtime has staged it)
+    HIP_TRY(c, hipStreamSynchronize(c->s_comm));
+    if (c->es == 4) {
+        const Relax<float> w = relax_of<float>(q);
+        HIP_TRY(c, hipMemcpyAsync((Relax<float>*)c->relax_dev + index, &w, sizeof(w), hipMemcpyHostToDevice, c->s_compute));
+    } else {
+        const Relax<double> w = relax_of<double>(q);
+        HIP_TRY(c, hipMemcpyAsync((Relax<double>*)c->relax_dev + index, &w, sizeof(w), hipMemcpyHostToDevice, c->s_compute));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->s_compute));
     return LBM_OK;
 }
@@ -851,20 +919,25 @@ int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int
     int rc = sync_all(c);
     if (rc) return rc;
     const size_t n = (size_t)c->geo.nx * c->geo.ny;
-    rc = ensure_stage(c, (size_t)12 * n * c->es);
+    rc = ensure_stage(c, (size_t)12 * n * c->es * c->batch);
     if (rc) return rc;
+    const size_t hes = host_dtype == LBM_F32 ? 4 : 8;
     if (u_host || rho_host) {
         rc = c->p.dtype == LBM_F32 ? export_macro_t<float>(c) : export_macro_t<double>(c);
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->s_compute));
-        if (u_host) { rc = stage_to_host(c, c->stage, u_host, host_dtype, 2); if (rc) return rc; }
-        if (rho_host) { rc = stage_to_host(c, (char*)c->stage + 2 * n * c->es, rho_host, host_dtype, 1); if (rc) return rc; }
+        for (int b = 0; b < c->batch; ++b) {   // staging of lattice b: [ux | uy | rho]; host: u[B][2][nx][NY], rho[B][nx][NY]
+            const char* st = (const char*)c->stage + (size_t)b * 3 * n * c->es;
+            const size_t hn = (size_t)c->geo.nx * c->geo.NY * hes;
+            if (u_host) { rc = stage_to_host(c, st, (char*)u_host + (size_t)b * 2 * hn, host_dtype, 2); if (rc) return rc; }
+            if (rho_host) { rc = stage_to_host(c, st + 2 * n * c->es, (char*)rho_host + (size_t)b * hn, host_dtype, 1); if (rc) return rc; }
+        }
     }
     if (fin_host) {
         rc = c->p.dtype == LBM_F32 ? export_fin_t<float>(c) : export_fin_t<double>(c);
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->s_compute));
-        rc = stage_to_host(c, c->stage, fin_host, host_dtype, Q);
+        rc = stage_to_host(c, c->stage, fin_host, host_dtype, Q * c->batch);
         if (rc) return rc;
     }
     return LBM_OK;
@@ -874,6 +947,7 @@ int lbm_halo_elems(const lbm_ctx* c) { return c ? 3 * c->geo.nx : 0; }
 
 int lbm_halo_export(lbm_ctx* c, int side, void* buf) {
     if (!c || !buf || (side != LBM_SIDE_LOW && side != LBM_SIDE_HIGH)) return fail(c, LBM_ERR_INVALID, "lbm_halo_export: bad argument");
+    if (c->batch > 1) return fail(c, LBM_ERR_STATE, "a batch of lattices has no slab halos");
     HIP_TRY(c, hipSetDevice(c->p.device));
     const int* pl = side_planes(side);
     const int row = side == LBM_SIDE_LOW ? 0 : c->geo.ny - 1;
@@ -886,6 +960,7 @@ int lbm_halo_export(lbm_ctx* c, int side, void* buf) {
 
 int lbm_halo_import(lbm_ctx* c, int side, const void* buf) {
     if (!c || !buf || (side != LBM_SIDE_LOW && side != LBM_SIDE_HIGH)) return fail(c, LBM_ERR_INVALID, "lbm_halo_import: bad argument");
+    if (c->batch > 1) return fail(c, LBM_ERR_STATE, "a batch of lattices has no slab halos");
     HIP_TRY(c, hipSetDevice(c->p.device));
     const int* pl = side_planes(side ^ 1);  // what arrives through `side` left the neighbour's opposite side
     const int row = side == LBM_SIDE_LOW ? -1 : c->geo.ny;
@@ -931,6 +1006,7 @@ int lbm_comm_unique_id(void* uid_out128) {
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     if (!c || !uid128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, LBM_ERR_INVALID, "lbm_comm_init: bad argument");
     if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
+    if (c->batch > 1) return fail(c, LBM_ERR_STATE, "a batch of lattices cannot be slab-decomposed");
     if (!rccl().ok) return fail(c, LBM_ERR_COMM, rccl().err);
     HIP_TRY(c, hipSetDevice(c->p.device));
     ncclUniqueId id;

@@ -42,8 +42,10 @@ class CavitySolver:
     """
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,
-                 device=0, rows=None, kernel="auto", layout="auto", omega_eps=None, omega_q=None):
+                 device=0, rows=None, kernel="auto", layout="auto", omega_eps=None, omega_q=None, batch=1):
         self._h = None
+        self.batch = int(batch)
+        self._lead = getattr(self, "_lead", ())      # leading axes of the host arrays: (B,) for a CavityBatch
         self.lib = L.lib()
         self.nx, self.ny = int(xsize), int(ysize)
         self.dtype = np.dtype(dtype)
@@ -58,6 +60,7 @@ class CavitySolver:
         if omega_q is None:
             omega_q = 1.2
         self.Re, self.RT, self.uLB, self.semantics = float(Re), RT, float(uLB), semantics
+        self._omega_eps, self._omega_q = omega_eps, omega_q
         self.relax = relaxation(self.Re, self.ny, self.uLB, omega_eps, omega_q)
         self.y0, self.ny_local = (0, self.ny) if rows is None else (int(rows[0]), int(rows[1]))
         p = L.lbm_params()
@@ -66,6 +69,7 @@ class CavitySolver:
         p.dtype, p.collision, p.semantics = _DT[self.dtype], _COLL[RT], _SEM[semantics]
         p.kernel, p.turb, p.device = _KERNEL[kernel], int(turb), int(device)
         p.layout = _LAYOUT[layout]
+        p.batch = self.batch
         p.uLB = self.uLB
         p.omega, p.omegam = self.relax["omega"], self.relax["omegam"]
         p.omega_e, p.omega_eps, p.omega_q = self.relax["omega_e"], self.relax["omega_eps"], self.relax["omega_q"]
@@ -98,6 +102,7 @@ class CavitySolver:
         self.close()
 
     def _host(self, a, shape, name):
+        shape = self._lead + tuple(shape)
         a = np.asarray(a)
         if a.dtype not in _DT or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
             raise ValueError(f"{name} must be a C-contiguous float32/float64 array of shape {shape}")
@@ -110,6 +115,18 @@ class CavitySolver:
     def set_state(self, fin):
         fin = self._host(fin, (9, self.nx, self.ny), "fin")
         self._check(self.lib.lbm_set_state(self._h, fin.ctypes.data, _DT[fin.dtype]), "lbm_set_state")
+
+    def set_relaxation(self, index=0, Re=None, **rates):
+        """Relaxation rates of lattice `index` for all later steps: from a Reynolds number (as the reference derives them,
+        MRT_GPU.py:63-93) and / or explicit omega, omegam, omega_e, omega_eps, omega_q."""
+        r = dict(self.relax if Re is None else relaxation(float(Re), self.ny, self.uLB, self._omega_eps, self._omega_q))
+        unknown = set(rates) - set(r)
+        if unknown:
+            raise ValueError(f"unknown relaxation rates {sorted(unknown)}")
+        r.update(rates)
+        self._check(self.lib.lbm_set_relaxation(self._h, int(index), r["omega"], r["omegam"], r["omega_e"], r["omega_eps"],
+                                                r["omega_q"]), "lbm_set_relaxation")
+        return r
 
     # -- time loop ----------------------------------------------------------------------
     def step(self, nsteps=1):
@@ -133,10 +150,11 @@ class CavitySolver:
         """Returns (u[2,X,Y], rho[X,Y]) (and fin[9,X,Y]).  Arrays are whole-lattice shaped;
         a slab writes only its rows y0:y0+ny_local."""
         dt = self.dtype if out_dtype is None else np.dtype(out_dtype)
-        u = np.zeros((2, self.nx, self.ny), dtype=dt) if u is None else self._host(u, (2, self.nx, self.ny), "u")
-        rho = np.zeros((self.nx, self.ny), dtype=dt) if rho is None else self._host(rho, (self.nx, self.ny), "rho")
+        lead = self._lead
+        u = np.zeros(lead + (2, self.nx, self.ny), dtype=dt) if u is None else self._host(u, (2, self.nx, self.ny), "u")
+        rho = np.zeros(lead + (self.nx, self.ny), dtype=dt) if rho is None else self._host(rho, (self.nx, self.ny), "rho")
         if want_fin and fin is None:
-            fin = np.zeros((9, self.nx, self.ny), dtype=dt)
+            fin = np.zeros(lead + (9, self.nx, self.ny), dtype=dt)
         if fin is not None:
             fin = self._host(fin, (9, self.nx, self.ny), "fin")
         self._check(self.lib.lbm_get_fields(self._h, u.ctypes.data, rho.ctypes.data,
@@ -192,6 +210,28 @@ class CavitySolver:
         g = ctypes.c_double(0.0)
         self._check(self.lib.lbm_copy_bandwidth(self._h, int(nbytes), int(iters), ctypes.byref(g)), "lbm_copy_bandwidth")
         return g.value
+
+
+class CavityBatch(CavitySolver):
+    """B independent cavities of the same size and scheme, one per Reynolds number, advanced by the same launches -- the
+    sweep MRT_GPU_datagen.py:55-57 runs one lattice after the other.  Host arrays carry a leading [B] axis:
+    fin[B,9,X,Y], u[B,2,X,Y], rho[B,X,Y].  Every lattice evolves exactly as it would alone."""
+
+    def __init__(self, xsize, ysize, Re_list, **kw):
+        self.Re_list = [float(r) for r in Re_list]
+        if not self.Re_list:
+            raise ValueError("Re_list is empty")
+        for bad in ("rows", "batch"):
+            if kw.get(bad) is not None:
+                raise ValueError(f"CavityBatch does not take `{bad}`")
+        self._lead = (len(self.Re_list),)
+        super().__init__(xsize, ysize, self.Re_list[0], batch=len(self.Re_list), **kw)
+        self.relax_list = [self.set_relaxation(i, Re=r) for i, r in enumerate(self.Re_list)]
+
+    def save_checkpoint(self, path):
+        raise NotImplementedError("checkpoint the lattices of a batch one by one through get_fields / set_state")
+
+    load_checkpoint = save_checkpoint
 
 
 def comm_unique_id():

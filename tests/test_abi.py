@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for n in declared_functions():
         assert hasattr(L, n), f"{n} declared in include/lbm.h but not exported"
-    assert _lib.lib().lbm_abi_version() == 1
+    assert _lib.lib().lbm_abi_version() == 2
 
 
 def test_library_has_no_static_rccl_dependency():
@@ -42,8 +42,9 @@ def test_library_has_no_static_rccl_dependency():
 
 
 def test_params_struct_layout():
-    assert ctypes.sizeof(_lib.lbm_params) == 12 * 4 + 6 * 8
-    assert _lib.lbm_params.uLB.offset == 48
+    assert ctypes.sizeof(_lib.lbm_params) == 14 * 4 + 6 * 8
+    assert _lib.lbm_params.batch.offset == 48
+    assert _lib.lbm_params.uLB.offset == 56
 
 
 def test_enums_match_header():
@@ -59,6 +60,7 @@ def test_null_arguments_are_rejected_not_dereferenced():
     L = _lib.lib()
     assert L.lbm_comm_unique_id(None) == -1            # LBM_ERR_INVALID
     assert L.lbm_step(None, 1) == -1
+    assert L.lbm_set_relaxation(None, 0, 1.0, 1.0, 1.0, 1.0, 1.0) == -1
     assert L.lbm_sync(None) == -1
     assert L.lbm_steps_done(None) == -1
     assert L.lbm_halo_elems(None) == 0

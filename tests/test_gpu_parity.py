@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle.lbm_ref import CavityOracleC, set_threads, max_threads      # noqa: E402
-from latticeboltzmannsimulations_amd import CavitySolver, ghia            # noqa: E402
+from latticeboltzmannsimulations_amd import CavityBatch, CavitySolver, ghia            # noqa: E402
 from latticeboltzmannsimulations_amd.slab import LocalSlabs, partition_rows  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -128,6 +128,13 @@ def test_two_and_three_steps_per_launch_agree(monkeypatch, dtype):
         with CavitySolver(260, 71, 400.0, RT=coll, semantics=sem, dtype=dtype, kernel="tb") as s:
             s.step(33)
             same(s, o, f"four steps {sem} {coll}")
+    # with the Smagorinsky closure: two-phase kernel (history through LDS) and in-place kernel (history in registers)
+    o = CavityOracleC(132, 99, 5000.0, semantics="mrt_gpu", collision="MRT", dtype=dtype, turb=1).step(29)
+    for steps in ("2", "3", "4", "5"):
+        monkeypatch.setenv("LBM_TB_STEPS", steps)
+        with CavitySolver(132, 99, 5000.0, RT="MRT", dtype=dtype, turb=1, kernel="tb") as s:
+            s.step(29)
+            same(s, o, f"turb LBM_TB_STEPS={steps}")
 
 
 def test_seeded_random_configurations_against_oracle():
@@ -249,6 +256,90 @@ def test_reynolds_sweep_datagen(tmp_path):
         o.step(int(its[i]))
         assert np.array_equal(f_final[i], o.fin) and np.array_equal(u_final[i], o.u), re
     assert (its == 2500).all()          # not converged within maxIt at tolerance 1e-7: the loop ran to its end
+    # a loose tolerance makes the lattices stop at different checks: each is recorded where the reference's loop
+    # (MRT_GPU_datagen.py:862-871), run on the oracle alone, would have stopped it
+    Re = np.array([100, 150, 400, 1000, 2500])
+    _, f2, u2, _, its2 = generate(Re, xsize=48, ysize=48, maxIt=6000, Pinterval=100, tolerance=2e-3, concurrent=4, save=False, quiet=True)
+    for i, re in enumerate(Re):
+        o = CavityOracleC(48, 48, float(re), semantics="mrt_gpu", collision="SRT", dtype=np.float32, turb=1)
+        count, past, It = 0, 0.0, 0
+        while True:
+            o.step(It + 1 - o.nsteps)
+            m = float(np.mean(o.u))
+            count += abs(m - past) / 0.08 < 2e-3
+            past = m
+            if count > 5:
+                break
+            if It + 100 > 6000 - 1:
+                o.step(6000 - o.nsteps)
+                break
+            It += 100
+        assert its2[i] == o.nsteps, (re, its2[i], o.nsteps)
+        assert np.array_equal(f2[i], o.fin) and np.array_equal(u2[i], o.u), re
+    assert len(set(its2.tolist())) > 1 and its2.min() < 6000
+
+
+@pytest.mark.parametrize("kernel", ["generic", "vec", "tb"])
+@pytest.mark.parametrize("dtype,coll,sem,turb", [(np.float32, "SRT", "mrt_gpu", 1), (np.float32, "MRT", "mrt_gpu", 0),
+                                                 (np.float64, "TRT", "mrt_gpu", 0), (np.float64, "MRT", "mrt_gpu", 1),
+                                                 (np.float64, "SRT", "mrt_py", 0)])
+def test_batch_of_lattices_equals_lattices_run_alone(kernel, dtype, coll, sem, turb):
+    """lbm_params.batch: B cavities with their own Reynolds numbers in one set of launches (the sweep of
+    MRT_GPU_datagen.py:55-57); every lattice must evolve bit for bit as the oracle runs it alone."""
+    if sem == "mrt_py" and kernel == "vec":
+        pytest.skip("the vector kernel implements MRT_GPU.py semantics only")
+    Res = [100.0, 400.0, 1000.0, 3200.0, 5000.0]
+    nx, ny = 132, 75
+    oracles = [CavityOracleC(nx, ny, Re, semantics=sem, collision=coll, dtype=dtype, turb=turb) for Re in Res]
+    with CavityBatch(nx, ny, Res, RT=coll, semantics=sem, dtype=dtype, turb=turb, kernel=kernel) as b:
+        def check(what, macros=True):
+            u, rho, fin = b.get_fields(want_fin=True)
+            assert fin.shape == (5, 9, nx, ny) and u.shape == (5, 2, nx, ny) and rho.shape == (5, nx, ny)
+            for i, o in enumerate(oracles):
+                assert np.array_equal(fin[i], o.fin), f"{what}: lattice {i} (Re {Res[i]}) fin differs"
+                if macros:
+                    assert np.array_equal(u[i], o.u) and np.array_equal(rho[i], o.rho), f"{what}: lattice {i} macros differ"
+        check("initial state", macros=False)
+        for n in (1, 2, 40):
+            b.step(n)
+            for o in oracles:
+                o.step(n)
+            check(f"after {oracles[0].nsteps} steps")
+        # upload of a whole batch, then new rates for one lattice mid-run
+        _, _, fin = b.get_fields(want_fin=True)
+        fin = np.ascontiguousarray(fin[::-1])                      # lattice i restarts from the state of lattice 4 - i
+        b.set_state(fin)
+        for i, o in enumerate(oracles):
+            o.set_state(fin[i])
+        r = b.set_relaxation(2, Re=250.0)
+        oracles[2] = CavityOracleC(nx, ny, 250.0, semantics=sem, collision=coll, dtype=dtype, turb=turb)
+        oracles[2].set_state(fin[2])
+        assert r["omega"] == pytest.approx(2.0 / (6.0 * 0.08 * ny / 250.0 + 1.0))
+        b.step(13)
+        for o in oracles:
+            o.step(13)
+        check("after set_state + set_relaxation")
+
+
+def test_batch_argument_checks():
+    with pytest.raises(RuntimeError, match="slab"):
+        CavitySolver(64, 64, 100.0, rows=(0, 32), batch=3)
+    with pytest.raises(ValueError):
+        CavityBatch(64, 64, [])
+    with CavityBatch(32, 32, [100.0, 200.0]) as b:
+        with pytest.raises(RuntimeError, match="index"):
+            b.set_relaxation(2, Re=100.0)
+        with pytest.raises(ValueError):
+            b.set_state(np.zeros((9, 32, 32), dtype=np.float32))      # the [B] axis is missing
+        with pytest.raises(RuntimeError, match="batch"):
+            b.halo_export(0, 0x1000)
+    with CavityBatch(32, 32, [100.0]) as one, CavitySolver(32, 32, 100.0) as ref:      # a batch of one
+        one.step(7); ref.step(7)
+        assert np.array_equal(one.get_fields(want_fin=True)[2][0], ref.get_fields(want_fin=True)[2])
+    with CavitySolver(32, 32, 100.0, dtype=np.float64) as s, CavitySolver(32, 32, 700.0, dtype=np.float64) as ref:
+        s.set_relaxation(0, Re=700.0)                                   # single lattice: rates changed at run time
+        s.step(9); ref.step(9)
+        assert np.array_equal(s.get_fields(want_fin=True)[2], ref.get_fields(want_fin=True)[2])
 
 
 def test_checkpoint_restart(tmp_path):
