@@ -13,6 +13,8 @@ COLL = {"SRT": 0, "TRT": 1, "MRT": 2}
 
 
 def build(force=False):
+    if os.environ.get("LBMREF_SO"):           # tests/test_oracle.py: the AddressSanitizer / UBSan build of the same source
+        return os.environ["LBMREF_SO"]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "lbm_ref.c")):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO

@@ -445,6 +445,63 @@ def test_converged_cavity_matches_ghia(Re, n, RT, dtype, tol):
     assert abs(fin.sum() - n * n) / (n * n) < 2e-2
 
 
+@pytest.mark.parametrize("sem,coll", [("mrt_gpu", "MRT"), ("mrt_gpu", "TRT"), ("mrt_py", "SRT")])
+def test_minimum_sizes_and_empty_calls(sem, coll):
+    """Edge cases: the smallest lattices the library accepts (4 x 4: every cell is a wall cell or next to one), two-row
+    slabs, and lbm_step(0)."""
+    for nx, ny in ((4, 4), (5, 4), (4, 7), (8, 5), (6, 6)):
+        for dtype in (np.float64, np.float32):
+            o = CavityOracleC(nx, ny, 100.0, semantics=sem, collision=coll, dtype=dtype)
+            with CavitySolver(nx, ny, 100.0, RT=coll, semantics=sem, dtype=dtype) as s:
+                s.step(0)
+                assert s.steps_done == 0 and np.array_equal(s.get_fields(want_fin=True)[2], o.fin)
+                for n in (1, 2, 22):
+                    o.step(n); s.step(n)
+                    same(s, o, f"{nx}x{ny} {sem} {coll} after {o.nsteps}")
+                s.step(0)
+                same(s, o, "after an empty step call")
+    nx, ny = 12, 8
+    o = CavityOracleC(nx, ny, 100.0, semantics=sem, collision=coll, dtype=np.float64).step(15)
+    slabs = [CavitySolver(nx, ny, 100.0, RT=coll, semantics=sem, dtype=np.float64, rows=(y0, 2)) for y0 in range(0, ny, 2)]
+    LocalSlabs(slabs).step(15)
+    u = np.zeros_like(o.u); rho = np.zeros_like(o.rho); fin = np.zeros_like(o.fin)
+    for s in slabs:
+        s.get_fields(u=u, rho=rho, fin=fin)
+        s.close()
+    assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho)
+
+
+def test_maximum_size_16384_fp32():
+    """Edge case 'maximum sizes': 16384 x 16384 fp32 = 268 M cells, element offsets beyond 2^31 in the [y][k][x] layout
+    (9.7 GB per lattice).  A smooth non-trivial state advanced 9 steps as ONE lattice (raw first step, one four-step
+    launch, single steps) must equal the same state advanced as two slabs of 8192 rows with one step per launch."""
+    n, steps = 16384, 9
+    x = np.arange(n, dtype=np.float32)
+    base = (1.0 + 1e-3 * np.sin(0.01 * x)[:, None] * np.cos(0.013 * x)[None, :]).astype(np.float32)
+    t = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float32)
+    fin0 = np.empty((9, n, n), dtype=np.float32)
+    for k in range(9):
+        np.multiply(base, t[k] * np.float32(1.0 + 1e-4 * k), out=fin0[k])
+    del base
+    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as one:
+        one.set_state(fin0)
+        one.step(steps)
+        u1, r1, f1 = one.get_fields(want_fin=True)
+    assert np.isfinite(f1[:, ::97, ::89]).all() and abs(float(r1[::64, ::64].mean()) - 1.0) < 1e-2
+    slabs = [CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, rows=r, kernel="vec") for r in partition_rows(n, 2)]
+    for s in slabs:
+        s.set_state(fin0)
+    del fin0
+    LocalSlabs(slabs).step(steps)
+    u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
+    for s in slabs:
+        s.get_fields(u=u, rho=rho, fin=fin)
+        s.close()
+    assert np.array_equal(rho, r1) and np.array_equal(u, u1)
+    for k in range(9):
+        assert np.array_equal(fin[k], f1[k]), k
+
+
 def test_fp32_tracks_fp64():
     with CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float64) as d, \
             CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float32) as f:

@@ -7,6 +7,7 @@ Parity status of the oracle itself: *parity unpinned at bit level* -- see oracle
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -15,6 +16,7 @@ from oracle import lbm_numpy as on
 from oracle.lbm_ref import CavityOracleC, set_threads, max_threads
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("sem", ["mrt_py", "mrt_gpu"])
@@ -174,3 +176,48 @@ def test_physics_pin_against_ghia_re100(sem, coll):
     ex, ey = ghia.profile_errors(o.u, 100, 0.08)
     assert ex < 0.06 and ey < 0.06, (ex, ey)
     assert ghia.r2_value(o.u, 100, 0.08) > 0.9
+
+
+def test_c_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The checker itself is checked: lbm_ref.c built with -fsanitize=address,undefined runs ragged and minimum-size cases
+    (both semantics, all collisions, turb, 1 and 3 threads) without a report and agrees with the NumPy restatement.
+    (Sanitizers exist for the CPU build only; GPU ASan is not available on the pool.)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan not installed")
+    src = os.path.join(ROOT, "oracle", "lbm_ref.c")
+    flags = ["-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fsanitize=address,undefined",
+             "-fno-sanitize-recover=undefined"]
+    objs = []
+    for suf, real, isf, extra in (("f64", "double", "0", ["-DLBMREF_DEFINE_THREADS"]), ("f32", "float", "1", [])):
+        o = str(tmp_path / f"lbm_ref_{suf}.o")
+        subprocess.check_call(["gcc"] + flags + [f"-DREAL={real}", f"-DSUF={suf}", f"-DREAL_IS_FLOAT={isf}"] + extra + ["-c", src, "-o", o])
+        objs.append(o)
+    so = str(tmp_path / "liblbmref_san.so")
+    subprocess.check_call(["gcc", "-shared", "-fopenmp", "-fsanitize=address,undefined"] + objs + ["-o", so, "-lm"])
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle.lbm_ref import CavityOracleC, set_threads
+from oracle.lbm_numpy import CavityOracle
+n = 0
+for threads in (1, 3):
+    set_threads(threads)
+    for sem, coll, turb in (("mrt_py", "SRT", 0), ("mrt_gpu", "SRT", 1), ("mrt_gpu", "TRT", 0), ("mrt_gpu", "MRT", 0), ("mrt_gpu", "MRT", 1)):
+        for nx, ny in ((4, 4), (5, 4), (4, 9), (33, 17)):
+            for dt in (np.float64, np.float32):
+                a = CavityOracleC(nx, ny, 400.0, semantics=sem, collision=coll, dtype=dt, turb=turb).step(12)
+                b = CavityOracle(nx, ny, 400.0, semantics=sem, collision=coll, dtype=dt, turb=turb).step(12)
+                assert np.array_equal(a.fin, b.fin) and np.array_equal(a.u, b.u) and np.array_equal(a.rho, b.rho), (sem, coll, turb, nx, ny)
+                n += 1
+print("sanitized cases ok:", n)
+""" % ROOT
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               LBMREF_SO=so)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sanitized cases ok: 80" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
