@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--arith", choices=["fast", "strict"], default="fast",
+                    help="fast: MRT operator in factored form with fused multiply-adds (agrees with the oracle to rounding, "
+                         "tests/test_gpu_parity.py::test_fast_arithmetic_*); strict: the reference's operation order "
+                         "(bit-identical to the oracle), also measured and reported under other.strict_arith")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short side measurements reported under 'other'")
@@ -152,7 +156,7 @@ def main():
         NY = ny_gpu
         rows = partition_rows(NY, world)[rank]
     solver = CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev,
-                          rows=rows if world > 1 else None, kernel=a.kernel)
+                          rows=rows if world > 1 else None, kernel=a.kernel, arith=a.arith)
     if world > 1:
         attach_rccl(solver, rank, world)
 
@@ -182,7 +186,7 @@ def main():
     es = np.dtype(dtype).itemsize
     mlups = cells_total * a.steps / dt / 1e6
     # algorithmic bytes per lattice update = read 9 + write 9 populations = 18 * sizeof(real).
-    # The dominant kernel (k_stepS_deep, S = 4 time steps per launch for fp32, 3 for fp64) performs S updates of every interior
+    # The dominant kernel (k_stepS_deep, S = 5 time steps per launch for fp32 fast, 4 strict, 3 for fp64) performs S updates of every interior
     # cell per launch; the K timed steps are about K/S such launches + 1..S single-step launches, bracketed by HIP events on
     # the compute stream.
     alg_bytes_step = cells_rank * 2 * 9 * es
@@ -195,7 +199,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(f"{a.config}:{world}:{a.kernel}", {}).get("hbm_bytes_per_step")
+                traffic = json.load(open(tp)).get(f"{a.config}:{world}:{a.kernel}:{a.arith}", {}).get("hbm_bytes_per_step")
             except Exception:
                 traffic = None
         other = {}
@@ -209,6 +213,12 @@ def main():
                 other["one_step_per_launch"] = {"MLUPS": round(cells_total / ms1 / 1e3, 1), "ms_per_step": round(ms1, 5),
                                                 "algorithmic_GBps": round(alg_bytes_step / ms1 / 1e6, 1),
                                                 "frac_of_peak": round(alg_bytes_step / ms1 / 1e6 / HBM_PEAK_GBPS, 4)}
+                if a.arith == "fast":     # the same workload in the reference's exact operation order (bit-identical to the oracle)
+                    with CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev, kernel=a.kernel, arith="strict") as s2:
+                        s2.step(40); s2.sync()
+                        ms2 = min(s2.time_steps(200) for _ in range(2)) / 200
+                    other["strict_arith"] = {"MLUPS": round(cells_total / ms2 / 1e3, 1), "ms_per_step": round(ms2, 5),
+                                             "algorithmic_GBps": round(alg_bytes_step / ms2 / 1e6, 1)}
                 # the headline input is the prescribed rest state; a developed flow toggles more bits and the
                 # arithmetic-limited three-step kernel then runs at a lower clock: same kernel on populations with +-1e-3
                 # relative noise (numpy default_rng(0)), fp32 noise field, 200 steps after 30 of warm-up
@@ -230,6 +240,8 @@ def main():
             "vs_baseline": None, "dtype": "f32" if dtype == "float32" else "f64", "data": "synthetic",
             "config": {"workload": label + (f"; {world} y-slabs of {nx}x{rows[1]}, lattice {nx}x{NY}" if world > 1 else ""),
                        "lattice": [nx, NY], "Re": Re, "collision": RT, "semantics": sem, "kernel": a.kernel,
+                       "arith": a.arith + (" (factored MRT operator + fused multiply-adds; same operator, agrees with the strict path "
+                                           "to rounding)" if a.arith == "fast" else " (reference operation order, bit-identical to the oracle)"),
                        "halo": "rccl send/recv inside lbm_step, overlapped" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,

@@ -42,6 +42,7 @@ enum { LBM_KERNEL_AUTO = 0,      /* fastest applicable: TB, else VEC, else GENER
        LBM_KERNEL_VEC = 2,       /* one step per launch, 16 B per access (MRT_GPU semantics) */
        LBM_KERNEL_TB = 3 };      /* two steps per launch on the interior through LDS + single steps on the frame */
 enum { LBM_LAYOUT_AUTO = 0, LBM_LAYOUT_PLANES = 1, LBM_LAYOUT_ROWS = 2 }; /* device arrays: [k][y][x] or [y][k][x] */
+enum { LBM_ARITH_STRICT = 0, LBM_ARITH_FAST = 1 };
 enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour towards smaller / larger y */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
@@ -64,7 +65,10 @@ typedef struct lbm_params {
                             the same launches, each with its own relaxation rates -- the Reynolds sweep that
                             MRT_GPU_datagen.py:55-57,879-902 runs one lattice after the other.  Host arrays gain a
                             leading [B] axis.  Not combinable with slabs. */
-    int32_t reserved;    /* 0 */
+    int32_t arith;       /* LBM_ARITH_STRICT (0, default): every operation in the reference's order, results bit-identical to
+                            the CPU restatement in oracle/.  LBM_ARITH_FAST: the MRT operator in an algebraically identical
+                            factored form (about half the arithmetic); results agree to rounding, not bit for bit.  SRT and
+                            TRT are unaffected. */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */
     double omega;        /* = omegap = omega_nu, MRT_GPU.py:65 */
     double omegam;       /* TRT, MRT_GPU.py:80 */

@@ -22,6 +22,7 @@ LBM_SEM_MRT_PY, LBM_SEM_MRT_GPU = 0, 1
 LBM_KERNEL_AUTO, LBM_KERNEL_GENERIC, LBM_KERNEL_VEC, LBM_KERNEL_TB = 0, 1, 2, 3
 LBM_LAYOUT_AUTO, LBM_LAYOUT_PLANES, LBM_LAYOUT_ROWS = 0, 1, 2
 LBM_SIDE_LOW, LBM_SIDE_HIGH = 0, 1
+LBM_ARITH_STRICT, LBM_ARITH_FAST = 0, 1
 
 
 class lbm_params(ctypes.Structure):
@@ -29,7 +30,7 @@ class lbm_params(ctypes.Structure):
                 ("y0", ctypes.c_int32), ("ny_local", ctypes.c_int32), ("dtype", ctypes.c_int32),
                 ("collision", ctypes.c_int32), ("semantics", ctypes.c_int32), ("kernel", ctypes.c_int32),
                 ("turb", ctypes.c_int32), ("device", ctypes.c_int32), ("layout", ctypes.c_int32),
-                ("batch", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("arith", ctypes.c_int32),
                 ("uLB", ctypes.c_double), ("omega", ctypes.c_double), ("omegam", ctypes.c_double),
                 ("omega_e", ctypes.c_double), ("omega_eps", ctypes.c_double), ("omega_q", ctypes.c_double)]
 

@@ -18,7 +18,9 @@ __host__ __device__ constexpr int cxk(int k) { return k == 1 || k == 5 || k == 8
 __host__ __device__ constexpr int cyk(int k) { return k == 2 || k == 5 || k == 6 ? 1 : (k == 4 || k == 7 || k == 8 ? -1 : 0); }
 
 enum { SEM_PY = 0, SEM_GPU = 1 };
-enum { C_SRT = 0, C_TRT = 1, C_MRT = 2 };
+enum { C_SRT = 0, C_TRT = 1, C_MRT = 2,
+       C_MRT_FAST = 3 };   // the MRT operator in factored form (lbm_params.arith = LBM_ARITH_FAST): not the reference's operation order
+constexpr bool coll_is_mrt(int c) { return c == C_MRT || c == C_MRT_FAST; }
 
 template <typename R>
 struct Relax {  // a2: MRT_GPU.py:63-93
@@ -124,6 +126,44 @@ __device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q
         fp[0] = f[0]; fm[0] = T{}; ep[0] = feq[0]; em[0] = T{};
 #pragma unroll
         for (int k = 0; k < Q; ++k) out[k] = (f[k] - w_nu * (fp[k] - ep[k])) - w.w_m * (fm[k] - em[k]);
+    } else if (COLL == C_MRT_FAST) {
+#pragma clang fp contract(fast)   // this branch only: the library is compiled with -ffp-contract=off
+        // The same operator, m = M f, m* = m - S (m - m_eq), f* = Minv m*, with the sums of M and Minv factored through the
+        // pairs f1 +- f3, f2 +- f4, f5 +- f7, f6 +- f8: ~100 operations per cell instead of ~190.  Algebraically identical
+        // to the branch below, NOT the reference's operation order, and multiply-adds are fused here: results differ from the
+        // strict form in the last bits
+        // (tolerances in tests/test_gpu_parity.py::test_fast_arithmetic_*).
+        const T a13 = f[1] + f[3], d13 = f[1] - f[3], a24 = f[2] + f[4], d24 = f[2] - f[4];
+        const T a57 = f[5] + f[7], d57 = f[5] - f[7], a68 = f[6] + f[8], d68 = f[6] - f[8];
+        const T sa = a13 + a24, sd = a57 + a68, dm = d57 - d68, dp = d57 + d68;
+        const T r = (f[0] + sa) + sd;                       // m0
+        const T jx = d13 + dm, jy = d24 + dp;               // m3, m5
+        const T f04 = (R)4 * f[0];
+        T e = ((R)2 * sd - sa) - f04;                       // m1
+        T eps = (f04 + sd) - (R)2 * sa;                     // m2
+        T qx = dm - (R)2 * d13, qy = dp - (R)2 * d24;       // m4, m6
+        T pxx = a13 - a24, pxy = a57 - a68;                 // m7, m8
+        const T jx2 = jx * jx, jy2 = jy * jy, j23 = (R)3 * (jx2 + jy2);
+        e = e - w.w_e * (e - (j23 - (R)2 * r));
+        eps = eps - w.w_eps * (eps - ((r - j23) + (R)9 * (jx2 * jy2)));
+        qx = qx - w.w_q * (qx - jx * ((R)3 * jx2 - (R)1));
+        qy = qy - w.w_q * (qy - jy * ((R)3 * jy2 - (R)1));
+        pxx = pxx - w_nu * (pxx - (jx2 - jy2));
+        pxy = pxy - w_nu * (pxy - jx * jy);
+        const R a9 = (R)(1.0 / 9), a36 = (R)(1.0 / 36), a18 = (R)(1.0 / 18), a6 = (R)(1.0 / 6),
+                a12 = (R)(1.0 / 12), a4 = (R)(1.0 / 4);
+        const T r9 = a9 * r;
+        out[0] = a9 * ((r - e) + eps);
+        const T A = (r9 - a36 * e) - a18 * eps, D = (r9 + a18 * e) + a36 * eps;
+        const T P = a4 * pxx, Pd = a4 * pxy;
+        const T bx = a6 * (jx - qx), by = a6 * (jy - qy);
+        const T Ap = A + P, Am = A - P, Dp = D + Pd, Dm = D - Pd;
+        const T X = a6 * jx + a12 * qx, Y = a6 * jy + a12 * qy;
+        const T XpY = X + Y, XmY = X - Y;
+        out[1] = Ap + bx; out[3] = Ap - bx;
+        out[2] = Am + by; out[4] = Am - by;
+        out[5] = Dp + XpY; out[7] = Dp - XpY;
+        out[8] = Dm + XmY; out[6] = Dm - XmY;
     } else {
         T m[Q], meq[Q];
         // rows of M_GS (MRT.py:163-173), left-to-right sums
@@ -386,7 +426,7 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
         R w_nu = w0.w_nu;
         if (TURB) w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
         R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
-        if (COLL != C_MRT || TURB) {   // the plain MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
+        if (!coll_is_mrt(COLL) || TURB) {   // the plain MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
             R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
             R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
             if (left || right) { ux = (R)0; uy = (R)0; }
@@ -434,7 +474,7 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
             f32x2 w_nu = (f32x2)(w0.w_nu);
             if (TURB) w_nu = smagorinsky_omega<f32x2>(g, p == 0 ? hq.xy : hq.zw, p == 0 ? hr.xy : hr.zw, w0.w_nu);
             const f32x2 rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
-            if (COLL != C_MRT || TURB) {
+            if (!coll_is_mrt(COLL) || TURB) {
                 const f32x2 ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
                 const f32x2 uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
                 equ<f32x2>(rho, ux, uy, fe);
@@ -460,7 +500,7 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
             R w_nu = w0.w_nu;
             if (TURB) w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
             const R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
-            if (COLL != C_MRT || TURB) {
+            if (!coll_is_mrt(COLL) || TURB) {
                 const R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
                 const R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
                 equ<R>(rho, ux, uy, fe);

@@ -355,7 +355,10 @@ void dispatch(const lbm_params& p, F&& f) {
         switch (p.collision) {
             case LBM_SRT: by_sem(real, std::integral_constant<int, C_SRT>{}); break;
             case LBM_TRT: by_sem(real, std::integral_constant<int, C_TRT>{}); break;
-            default: by_sem(real, std::integral_constant<int, C_MRT>{}); break;
+            default:
+                if (p.arith == LBM_ARITH_FAST) by_sem(real, std::integral_constant<int, C_MRT_FAST>{});
+                else by_sem(real, std::integral_constant<int, C_MRT>{});
+                break;
         }
     };
     if (p.dtype == LBM_F32) by_coll(float{});
@@ -719,7 +722,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return bail("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
     if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_TB) return bail("bad kernel variant");
     if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
-    if (p->batch < 0 || p->batch > 65535 || p->reserved != 0) return bail("batch must be 0 .. 65535 (and reserved 0)");
+    if (p->batch < 0 || p->batch > 65535) return bail("batch must be 0 .. 65535");
+    if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return bail("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
     if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return bail("a batch of lattices cannot be slab-decomposed");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -766,7 +770,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // with the closure (perf23.log, 4096^2 fp32, S = 2 / 3 / 4): SRT 108 / 150 / 162, TRT 110 / 145 / 124 (S = 4 spills
         // under the 128-register occupancy floor), MRT 109 / 111 / 115; fp64 SRT 57 / 81 / 83, MRT 61 / 72 / 73
         const bool trt_turb = p->turb && p->collision == LBM_TRT;
-        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 && !trt_turb ? 4 : 3);
+        // factored MRT operator (arith = FAST; perf28.log, perf29.log): at S = 5 the strict form is arithmetic-bound (209 GLUPS,
+        // as at S = 4), the factored one is not: S = 3 / 4 / 5 = 176 / 217 / 252-261 GLUPS
+        const bool fast_mrt = p->arith == LBM_ARITH_FAST && p->collision == LBM_MRT;
+        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 && !trt_turb ? (fast_mrt ? 5 : 4) : 3);
         const bool deep_ok = p->dtype == LBM_F32 && p->nx >= 64 && p->ny_local >= 64;
         c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
         c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width

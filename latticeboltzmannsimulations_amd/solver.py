@@ -12,6 +12,7 @@ _DT = {np.dtype(np.float32): L.LBM_F32, np.dtype(np.float64): L.LBM_F64}
 _COLL = {"SRT": L.LBM_SRT, "TRT": L.LBM_TRT, "MRT": L.LBM_MRT}
 _SEM = {"mrt_py": L.LBM_SEM_MRT_PY, "mrt_gpu": L.LBM_SEM_MRT_GPU}
 _KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC, "tb": L.LBM_KERNEL_TB}
+_ARITH = {"strict": L.LBM_ARITH_STRICT, "fast": L.LBM_ARITH_FAST}
 _LAYOUT = {"auto": L.LBM_LAYOUT_AUTO, "planes": L.LBM_LAYOUT_PLANES, "rows": L.LBM_LAYOUT_ROWS}
 
 
@@ -39,10 +40,12 @@ class CavitySolver:
     kernel       : 'auto' | 'generic' (one thread per cell) | 'vec' (16 B per access, MRT_GPU.py semantics) |
                    'tb' (two steps per launch on the interior through LDS; what 'auto' picks when it applies)
     layout       : device arrays 'planes' [k][y][x], 'rows' [y][k][x], 'auto' (= rows)
+    arith        : 'strict' (default; the reference's operation order, bit-identical to the CPU restatement the tests check against) or 'fast' (MRT operator
+                   in factored form, about half the arithmetic, agrees to rounding)
     """
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,
-                 device=0, rows=None, kernel="auto", layout="auto", omega_eps=None, omega_q=None, batch=1):
+                 device=0, rows=None, kernel="auto", layout="auto", omega_eps=None, omega_q=None, batch=1, arith="strict"):
         self._h = None
         self.batch = int(batch)
         self._lead = getattr(self, "_lead", ())      # leading axes of the host arrays: (B,) for a CavityBatch
@@ -70,6 +73,7 @@ class CavitySolver:
         p.kernel, p.turb, p.device = _KERNEL[kernel], int(turb), int(device)
         p.layout = _LAYOUT[layout]
         p.batch = self.batch
+        p.arith = _ARITH[arith]
         p.uLB = self.uLB
         p.omega, p.omegam = self.relax["omega"], self.relax["omegam"]
         p.omega_e, p.omega_eps, p.omega_q = self.relax["omega_e"], self.relax["omega_eps"], self.relax["omega_q"]

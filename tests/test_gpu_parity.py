@@ -421,12 +421,13 @@ def test_slab_restart_from_global_state():
     assert np.array_equal(fin, f35) and np.array_equal(u, u35) and np.array_equal(rho, r35)
 
 
-@pytest.mark.parametrize("Re,n,RT,dtype,tol", [(100, 128, "MRT", np.float64, 0.03), (1000, 256, "MRT", np.float32, 0.05),
-                                               (1000, 256, "SRT", np.float64, 0.05)])
-def test_converged_cavity_matches_ghia(Re, n, RT, dtype, tol):
+@pytest.mark.parametrize("Re,n,RT,dtype,tol,arith", [(100, 128, "MRT", np.float64, 0.03, "strict"), (1000, 256, "MRT", np.float32, 0.05, "strict"),
+                                                     (1000, 256, "SRT", np.float64, 0.05, "strict"), (1000, 256, "MRT", np.float32, 0.05, "fast"),
+                                                     (100, 128, "MRT", np.float64, 0.03, "fast")])
+def test_converged_cavity_matches_ghia(Re, n, RT, dtype, tol, arith):
     """T7 (physics): run to the reference's convergence criterion (MRT_GPU.py:883-889) and compare the centrelines
     with Ghia et al. at the geometrically correct positions; global mass drift stays small."""
-    with CavitySolver(n, n, float(Re), RT=RT, dtype=dtype) as s:
+    with CavitySolver(n, n, float(Re), RT=RT, dtype=dtype, arith=arith) as s:
         prev, quiet = None, 0
         for _ in range(400):
             s.step(3000)
@@ -500,6 +501,56 @@ def test_maximum_size_16384_fp32():
     assert np.array_equal(rho, r1) and np.array_equal(u, u1)
     for k in range(9):
         assert np.array_equal(fin[k], f1[k]), k
+
+
+@pytest.mark.parametrize("kernel", ["generic", "vec", "tb"])
+@pytest.mark.parametrize("turb", [0, 1])
+def test_fast_arithmetic_agrees_with_oracle_to_rounding(kernel, turb, monkeypatch):
+    """arith='fast': the MRT operator in factored form with fused multiply-adds -- algebraically the same operator, not the
+    reference's operation order, so the comparison with the oracle is by tolerance: fp64 full field
+    <= 1e-9 relative after 10 steps; fp32 <= 1e-4 relative to the fp64 oracle after 100 steps (and <= 2e-5 to the fp32 one).
+    Every kernel variant and all steps-per-launch settings of the multi-step kernel."""
+    nx, ny = 132, 99
+    for tbs in (("2", "3", "4", "5") if kernel == "tb" else ("",)):
+        if tbs:
+            monkeypatch.setenv("LBM_TB_STEPS", tbs)
+        a64 = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision="MRT", dtype=np.float64, turb=turb)
+        a32 = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision="MRT", dtype=np.float32, turb=turb)
+        with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=np.float64, turb=turb, kernel=kernel, arith="fast") as d, \
+                CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=np.float32, turb=turb, kernel=kernel, arith="fast") as f:
+            d.step(10); a64.step(10)
+            u, rho, fin = d.get_fields(want_fin=True)
+            assert not np.array_equal(fin, a64.fin)                           # it really is the other operation order
+            assert np.abs(fin - a64.fin).max() / np.abs(a64.fin).max() < 1e-9
+            assert np.abs(u - a64.u).max() / 0.08 < 1e-9 and np.abs(rho - a64.rho).max() < 1e-9
+            d.step(90); a64.step(90); f.step(100); a32.step(100)
+            u, rho, fin = d.get_fields(want_fin=True)
+            assert np.abs(fin - a64.fin).max() / np.abs(a64.fin).max() < 1e-9
+            u32, rho32, fin32 = f.get_fields(want_fin=True, out_dtype=np.float64)
+            assert np.abs(fin32 - a64.fin).max() / np.abs(a64.fin).max() < 1e-4
+            assert np.abs(u32 - a64.u).max() / 0.08 < 1e-3                     # fp32 itself is this far from fp64
+            assert np.abs(fin32 - a32.fin).max() / np.abs(a32.fin).max() < 2e-5
+            assert np.abs(u32 - a32.u).max() / 0.08 < 2e-4
+
+
+def test_fast_arithmetic_config_c1_centrelines():
+    """north_star's tolerance on the fast path: 128 x 128, Re = 100, fp64, 1000 steps (config C1 with the MRT operator):
+    centreline velocities within 1e-6 relative of the oracle's; collisions conserve mass as exactly as the strict form."""
+    n = 128
+    o = CavityOracleC(n, n, 100.0, semantics="mrt_gpu", collision="MRT", dtype=np.float64).step(1000)
+    with CavitySolver(n, n, 100.0, RT="MRT", dtype=np.float64, arith="fast") as s:
+        s.step(1000)
+        u, rho, fin = s.get_fields(want_fin=True)
+    for got, ref in ((u[0, n // 2, :], o.u[0, n // 2, :]), (u[1, :, n // 2], o.u[1, :, n // 2])):
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6
+    assert np.abs(fin - o.fin).max() / np.abs(o.fin).max() < 1e-9
+    assert abs(fin.sum() - o.fin.sum()) / o.fin.sum() < 1e-12
+    with CavityBatch(96, 64, [100.0, 1000.0], RT="MRT", dtype=np.float64, arith="fast") as b:      # in a batch as well
+        b.step(40)
+        fb = b.get_fields(want_fin=True)[2]
+    for i, Re in enumerate((100.0, 1000.0)):
+        ob = CavityOracleC(96, 64, Re, semantics="mrt_gpu", collision="MRT", dtype=np.float64).step(40)
+        assert np.abs(fb[i] - ob.fin).max() / np.abs(ob.fin).max() < 1e-9
 
 
 def test_fp32_tracks_fp64():
