@@ -11,6 +11,8 @@ namespace lbm {
 
 constexpr int Q = 9;
 constexpr int GH = 4;  // ghost/pad columns on each side of a row (keeps x = 0 16-byte aligned)
+constexpr int GHY = 6; // ghost rows above and below a lattice: row -1 / ny is the one-row halo of a slab (and holds parked wall data);
+                       // rows -5 .. -1 / ny .. ny+4 receive the neighbour's rows for the multi-step launches (deep halo)
 
 // a1: lattice vectors, MRT.py:138-140 (k: 0 rest, 1 E, 2 N, 3 W, 4 S, 5 NE, 6 NW, 7 SW, 8 SE).
 // A population moves from (x, y) to (x + cx, y - cy): y = 0 is the lid (MRT_GPU.py:412-413).
@@ -100,6 +102,11 @@ __device__ __forceinline__ void macros(const R (&f)[Q], int x, int gy, int X, in
     }
 }
 
+// fused multiply-add on a scalar real or on two packed cells (v_fma_f32 / v_fma_f64 / v_pk_fma_f32): one rounding, lane-wise
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // a6: collision.  SRT MRT.py:396 / MRT_GPU.py:413; TRT MRT_GPU.py:455-462,514-525;
 // MRT MRT_GPU.py:633-655 (m = M f with jx = m3, jy = m5 from the raw populations, the
 // reference's own m_eq polynomial, f* = Minv m).  Zero matrix entries are skipped and the
@@ -127,38 +134,37 @@ __device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q
 #pragma unroll
         for (int k = 0; k < Q; ++k) out[k] = (f[k] - w_nu * (fp[k] - ep[k])) - w.w_m * (fm[k] - em[k]);
     } else if (COLL == C_MRT_FAST) {
-#pragma clang fp contract(fast)   // this branch only: the library is compiled with -ffp-contract=off
         // The same operator, m = M f, m* = m - S (m - m_eq), f* = Minv m*, with the sums of M and Minv factored through the
-        // pairs f1 +- f3, f2 +- f4, f5 +- f7, f6 +- f8: ~100 operations per cell instead of ~190.  Algebraically identical
-        // to the branch below, NOT the reference's operation order, and multiply-adds are fused here: results differ from the
-        // strict form in the last bits
-        // (tolerances in tests/test_gpu_parity.py::test_fast_arithmetic_*).
+        // pairs f1 +- f3, f2 +- f4, f5 +- f7, f6 +- f8 and explicit fused multiply-adds: ~75 operations per cell instead of
+        // ~190.  Algebraically identical to the branch below, NOT the reference's operation order: results differ from the
+        // strict form in the last bits (tolerances in tests/test_gpu_parity.py::test_fast_arithmetic_*).  The operations are
+        // spelled out (no compiler contraction), so every kernel variant performs the same ones and a lattice gives the same
+        // bits however it is cut into tiles, frames or slabs.
         const T a13 = f[1] + f[3], d13 = f[1] - f[3], a24 = f[2] + f[4], d24 = f[2] - f[4];
         const T a57 = f[5] + f[7], d57 = f[5] - f[7], a68 = f[6] + f[8], d68 = f[6] - f[8];
         const T sa = a13 + a24, sd = a57 + a68, dm = d57 - d68, dp = d57 + d68;
-        const T r = (f[0] + sa) + sd;                       // m0
-        const T jx = d13 + dm, jy = d24 + dp;               // m3, m5
+        const T r = (f[0] + sa) + sd;                                       // m0
+        const T jx = d13 + dm, jy = d24 + dp;                               // m3, m5
         const T f04 = (R)4 * f[0];
-        T e = ((R)2 * sd - sa) - f04;                       // m1
-        T eps = (f04 + sd) - (R)2 * sa;                     // m2
-        T qx = dm - (R)2 * d13, qy = dp - (R)2 * d24;       // m4, m6
-        T pxx = a13 - a24, pxy = a57 - a68;                 // m7, m8
+        T e = fma_(T((R)2), sd, -sa) - f04;                                 // m1
+        T eps = fma_(T((R)-2), sa, f04 + sd);                               // m2
+        T qx = fma_(T((R)-2), d13, dm), qy = fma_(T((R)-2), d24, dp);       // m4, m6
+        T pxx = a13 - a24, pxy = a57 - a68;                                 // m7, m8
         const T jx2 = jx * jx, jy2 = jy * jy, j23 = (R)3 * (jx2 + jy2);
-        e = e - w.w_e * (e - (j23 - (R)2 * r));
-        eps = eps - w.w_eps * (eps - ((r - j23) + (R)9 * (jx2 * jy2)));
-        qx = qx - w.w_q * (qx - jx * ((R)3 * jx2 - (R)1));
-        qy = qy - w.w_q * (qy - jy * ((R)3 * jy2 - (R)1));
-        pxx = pxx - w_nu * (pxx - (jx2 - jy2));
-        pxy = pxy - w_nu * (pxy - jx * jy);
+        e = fma_(T(-w.w_e), e - fma_(T((R)-2), r, j23), e);
+        eps = fma_(T(-w.w_eps), eps - fma_(T((R)9), jx2 * jy2, r - j23), eps);
+        qx = fma_(T(-w.w_q), qx - jx * fma_(T((R)3), jx2, T((R)-1)), qx);
+        qy = fma_(T(-w.w_q), qy - jy * fma_(T((R)3), jy2, T((R)-1)), qy);
+        pxx = fma_(-w_nu, pxx - (jx2 - jy2), pxx);
+        pxy = fma_(-w_nu, fma_(-jx, jy, pxy), pxy);
         const R a9 = (R)(1.0 / 9), a36 = (R)(1.0 / 36), a18 = (R)(1.0 / 18), a6 = (R)(1.0 / 6),
                 a12 = (R)(1.0 / 12), a4 = (R)(1.0 / 4);
         const T r9 = a9 * r;
         out[0] = a9 * ((r - e) + eps);
-        const T A = (r9 - a36 * e) - a18 * eps, D = (r9 + a18 * e) + a36 * eps;
-        const T P = a4 * pxx, Pd = a4 * pxy;
+        const T A = fma_(T(-a18), eps, fma_(T(-a36), e, r9)), D = fma_(T(a36), eps, fma_(T(a18), e, r9));
+        const T Ap = fma_(T(a4), pxx, A), Am = fma_(T(-a4), pxx, A), Dp = fma_(T(a4), pxy, D), Dm = fma_(T(-a4), pxy, D);
         const T bx = a6 * (jx - qx), by = a6 * (jy - qy);
-        const T Ap = A + P, Am = A - P, Dp = D + Pd, Dm = D - Pd;
-        const T X = a6 * jx + a12 * qx, Y = a6 * jy + a12 * qy;
+        const T X = fma_(T(a12), qx, a6 * jx), Y = fma_(T(a12), qy, a6 * jy);
         const T XpY = X + Y, XmY = X - Y;
         out[1] = Ap + bx; out[3] = Ap - bx;
         out[2] = Am + by; out[4] = Am - by;
@@ -276,9 +282,9 @@ __device__ __forceinline__ void wall_rules(R (&g)[Q], const R (&fe)[Q], int x, i
     }
 }
 
-// Addressing of the nine direction arrays.  Local row y in [-1, ny], column x in [-GH, nx+GH).
+// Addressing of the nine direction arrays.  Local row y in [-GHY, ny+GHY), column x in [-GH, nx+GH).
 // Element (k, x, y) lives at k * plane + at(x, y).  Two layouts share this formula:
-//   planes  [k][y][x]: plane = pitch * (ny + 2), row = pitch       (nine separate arrays)
+//   planes  [k][y][x]: plane = pitch * (ny + 2 GHY), row = pitch   (nine separate arrays)
 //   rows    [y][k][x]: plane = pitch,            row = 9 * pitch   (the nine rows y of the nine
 //                                                                   directions are adjacent)
 // Every row of every direction is contiguous and 16-byte aligned in both.
@@ -288,7 +294,7 @@ struct Geo {
     int pitch;        // elements per row (nx + 2*GH, multiple of 4)
     int nx, ny;       // columns, local rows
     int y0, NY;       // first global row of this slab, global height
-    __host__ __device__ __forceinline__ long long at(int x, int y) const { return (long long)(y + 1) * row + GH + x; }
+    __host__ __device__ __forceinline__ long long at(int x, int y) const { return (long long)(y + GHY) * row + GH + x; }
 };
 
 // Where a perimeter cell parks the density of its last macroscopic state: slot 0 of the

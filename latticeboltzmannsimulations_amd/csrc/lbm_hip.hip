@@ -121,16 +121,20 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
 
 // One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
 // [nx-W, nx) of the rows in between.  One thread per cell, complete wall / kept-slot logic.
+// elo / ehi: the row strips start elo rows above row 0 / end ehi rows below row ny - 1, in the ghost rows that hold the
+// neighbour slab's rows (deep halo: the passes of a multi-step recompute a shrinking band of the neighbour's rows instead of
+// exchanging one row per pass).
 template <typename R, int COLL, int SEM, bool TURB>
-__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, Batch<R> bt, int W) {
+__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, Batch<R> bt, int W, int elo, int ehi) {
     LBM_BATCH_SELECT(blockIdx.y)
     const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
-    const long long nrow = 2LL * W * geo.nx, ncol = 2LL * W * (geo.ny - 2 * W);
+    const long long ntop = (long long)(W + elo) * geo.nx, nbot = (long long)(W + ehi) * geo.nx;
+    const long long nrow = ntop + nbot, ncol = 2LL * W * (geo.ny - 2 * W);
     int x, y;
     if (t < nrow) {
-        const int strip = (int)(t / ((long long)W * geo.nx)), o = (int)(t % ((long long)W * geo.nx));
+        const int o = (int)(t < ntop ? t : t - ntop);
         x = o % geo.nx;
-        y = (strip == 0 ? 0 : geo.ny - W) + o / geo.nx;
+        y = (t < ntop ? -elo : geo.ny - W) + o / geo.nx;
     } else if (t < nrow + ncol) {
         const long long u = t - nrow, half = (long long)W * (geo.ny - 2 * W);
         const int strip = (int)(u / half), o = (int)(u % half);
@@ -243,6 +247,8 @@ struct lbm_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
+    bool deep_pending = false;  // ... and it was a deep one (tb_steps complete rows per side, for the next multi-step)
+    bool deep_halo = false;     // multi-steps between slabs exchange once per launch (MRT_GPU semantics; LBM_DEEP_HALO=0 disables)
     bool loopback = false;      // diagnostic: 1-rank communicator, the slab exchanges halos with itself
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
@@ -393,13 +399,13 @@ int launch_rows(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
 }
 
 // One single step on the frame of width W, lat[from] -> lat[to] (part of a double step; never a raw lattice).
-int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s) {
+int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0, int ehi = 0) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
-        const long long cells = 2LL * W * c->geo.nx + 2LL * W * (c->geo.ny - 2 * W);
+        const long long cells = (2LL * W + elo + ehi) * c->geo.nx + 2LL * W * (c->geo.ny - 2 * W);
         hipLaunchKernelGGL((k_step_frame<R, VT::COLL, VT::SEM, VT::TURB>), dim3((unsigned)((cells + BLK - 1) / BLK), c->batch), dim3(BLK), 0, s,
-                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), W);
+                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), W, elo, ehi);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -526,6 +532,45 @@ int enqueue_exchange(lbm_ctx* c, int which) {
     return LBM_OK;
 }
 
+// Deep halo for a multi-step of S steps: the S complete rows (all planes, ghost columns included) next to each interface go to
+// the neighbour's ghost rows in ONE message per side; the S frame passes then recompute a shrinking band of the neighbour's
+// rows (rows -(S - i) .. for pass i) instead of exchanging one row per pass.  RCCL's latency per exchange, not its bandwidth,
+// is what the per-pass scheme cannot hide: 739 KB once instead of 5 x 48 KB.  MRT_GPU semantics only: there a
+// side-wall cell overwrites the slots it does not stream by the wall rule, so nothing a cell needs lives in the ghost columns
+// of a ghost row (MRT.py's left wall reads parked values).
+int enqueue_deep_exchange(lbm_ctx* c, int which, int S) {
+    static const bool skip = std::getenv("LBM_DEBUG_SKIP_EXCHANGE") != nullptr;   // timing diagnostic only: wrong results
+    if (skip) return LBM_OK;
+    const ncclDataType_t dt = c->p.dtype == LBM_F32 ? ncclFloat : ncclDouble;
+    const int ny = c->geo.ny, nplanes = c->p.turb ? Q + 2 : Q;
+    const bool rows_layout = c->geo.row != c->geo.pitch;
+    auto block = [&](int r0, int k) {
+        return (char*)c->lat[which] + ((size_t)k * c->geo.plane + (size_t)(r0 + GHY) * c->geo.row) * c->es;
+    };
+    NCCL_TRY(c, rccl().GroupStart());
+    for (int side = 0; side < 2; ++side) {
+        int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
+        if (c->loopback) peer = 0;
+        if (peer < 0 || peer >= c->nranks) continue;
+        const int sside = c->loopback ? (side ^ 1) : side;   // see enqueue_exchange
+        const int send_r0 = sside == LBM_SIDE_LOW ? 0 : ny - S;
+        const int recv_r0 = side == LBM_SIDE_LOW ? -S : ny;
+        if (rows_layout) {   // [y][k][x]: S rows of all planes are one contiguous block
+            const size_t n = (size_t)S * c->geo.row;
+            NCCL_TRY(c, rccl().Send(block(send_r0, 0), n, dt, peer, c->comm, c->s_comm));
+            NCCL_TRY(c, rccl().Recv(block(recv_r0, 0), n, dt, peer, c->comm, c->s_comm));
+        } else {
+            const size_t n = (size_t)S * c->geo.pitch;
+            for (int k = 0; k < nplanes; ++k) {
+                NCCL_TRY(c, rccl().Send(block(send_r0, k), n, dt, peer, c->comm, c->s_comm));
+                NCCL_TRY(c, rccl().Recv(block(recv_r0, k), n, dt, peer, c->comm, c->s_comm));
+            }
+        }
+    }
+    NCCL_TRY(c, rccl().GroupEnd());
+    return LBM_OK;
+}
+
 // Every step unit (one single step or one double step) follows one protocol on the two streams:
 //   s_comm    (highest priority): waits ev_int (interior work of the previous unit), runs the wall / slab-edge work of
 //                                 this unit and the RCCL exchanges, records ev_edges;
@@ -551,6 +596,7 @@ int single_step(lbm_ctx* c, bool* comm_used) {
         rc = enqueue_exchange(c, c->cur);
         if (rc) return rc;
         c->halo_pending = true;
+        c->deep_pending = false;
         *comm_used = true;
         return LBM_OK;
     }
@@ -564,29 +610,35 @@ int single_step(lbm_ctx* c, bool* comm_used) {
 
 // S = c->tb_steps steps: lat[a] (state n) -> lat[b] (state n+S).  Bulk: the deep-interior kernel on cells >= TB_F away
 // from walls and slab edges.  Frame: S ordinary single steps on strips of decreasing width (TB_F + S - i for pass i; pass i+1
-// pulls from one cell further out than it writes), through the scratch lattices, the last one into lat[b].  Between slabs
-// every pass needs its own halo, so there are S exchanges per multi-step.
-int multi_step(lbm_ctx* c, bool* comm_used) {
+// pulls from one cell further out than it writes), through the scratch lattices, the last one into lat[b].
+// Between slabs the frame passes and the exchanges share the second stream, beside the tile kernel.  With the deep halo
+// (MRT_GPU semantics) the row strips of pass i start S - i rows inside the neighbour's rows received before the unit, and the
+// only exchange is the one for the next unit; otherwise every pass is followed by a one-row exchange.  (Running row and
+// column strips as separate launches on separate streams was measured and lost 8 %: profiles/r01_logs/perf31.log, perf35.log.)
+int multi_step(lbm_ctx* c, bool* comm_used, bool next_is_multi) {
     const bool multi = c->nranks > 1 || c->loopback;
+    const bool deep = multi && c->deep_halo;
     const int S = c->tb_steps, a = c->cur, b = c->cur ^ 1;
     HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // this unit's tile kernel needs the previous unit's frame
     int rc;
-    if (multi && !c->halo_pending) {
-        rc = enqueue_exchange(c, a);
+    int from = a;
+    if (multi && (deep ? !c->deep_pending : !c->halo_pending)) {
+        rc = deep ? enqueue_deep_exchange(c, a, S) : enqueue_exchange(c, a);
         if (rc) return rc;
     }
-    int from = a;
+    const bool has_lo = multi && (c->loopback || c->rank > 0), has_hi = multi && (c->loopback || c->rank < c->nranks - 1);
     for (int i = 1; i <= S; ++i) {
         const int to = i == S ? b : 2 + ((i - 1) & 1);
-        rc = launch_frame(c, from, to, c->tb_f + S - i, c->s_comm);
+        const int ext = deep ? S - i : 0;
+        rc = launch_frame(c, from, to, c->tb_f + S - i, c->s_comm, has_lo ? ext : 0, has_hi ? ext : 0);
         if (rc) return rc;
-        if (multi && i < S) {
+        if (multi && !deep && i < S) {
             rc = enqueue_exchange(c, to);
             if (rc) return rc;
         }
         from = to;
     }
-    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
     HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
     rc = launch_deep(c, a, b, c->s_compute);
     if (rc) return rc;
@@ -594,10 +646,12 @@ int multi_step(lbm_ctx* c, bool* comm_used) {
     c->cur ^= 1;
     c->raw[c->cur] = 0;
     c->nsteps += S;
-    if (multi) {
-        rc = enqueue_exchange(c, c->cur);
+    if (multi) {   // the halo of the next unit, behind the last row strips and beside this unit's tile kernel
+        const bool deep_next = deep && next_is_multi;
+        rc = deep_next ? enqueue_deep_exchange(c, c->cur, S) : enqueue_exchange(c, c->cur);
         if (rc) return rc;
         c->halo_pending = true;
+        c->deep_pending = deep_next;
     }
     *comm_used = true;
     return LBM_OK;
@@ -612,7 +666,10 @@ int step_many(lbm_ctx* c, int nsteps) {
         // The first step after an upload reads raw populations, and the LAST step of a call is always a single step:
         // lbm_get_fields needs the lattice of the step before the last for the one-step lag of u / rho.
         int rc;
-        if (c->use_tb && !c->raw[c->cur] && left >= c->tb_steps + 1) { rc = multi_step(c, &comm_used); left -= c->tb_steps; }
+        if (c->use_tb && !c->raw[c->cur] && left >= c->tb_steps + 1) {
+            rc = multi_step(c, &comm_used, left - c->tb_steps >= c->tb_steps + 1);
+            left -= c->tb_steps;
+        }
         else { rc = single_step(c, &comm_used); left -= 1; }
         if (rc) return rc;
     }
@@ -742,14 +799,14 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     c->geo.pitch = ((p->nx + 2 * GH) + 3) / 4 * 4;
     const int nplanes = p->turb ? Q + 2 : Q;   // + the two Smagorinsky history planes
     if (p->layout == LBM_LAYOUT_PLANES) {
-        c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2);
+        c->geo.plane = (long long)c->geo.pitch * (p->ny_local + 2 * GHY);
         c->geo.row = c->geo.pitch;
     } else {  // LBM_LAYOUT_ROWS (default): +10 % on the 18-stream pattern, see DESIGN.md
         c->geo.plane = c->geo.pitch;
         c->geo.row = (long long)nplanes * c->geo.pitch;
     }
     c->batch = p->batch > 1 ? p->batch : 1;
-    c->bstride = (long long)nplanes * c->geo.pitch * (p->ny_local + 2);   // lattice z of a batch starts z * bstride elements in
+    c->bstride = (long long)nplanes * c->geo.pitch * (p->ny_local + 2 * GHY);   // lattice z of a batch starts z * bstride elements in
     const size_t bytes = (size_t)c->bstride * c->batch * c->es;
     {
         const int V = 16 / c->es;
@@ -781,6 +838,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  LBM_TB3_WIDE=1 selects 30 x 12.
         const char* shp = std::getenv("LBM_TB3_WIDE");
         c->tb3_wide = shp && std::atoi(shp) != 0;
+        const char* dh = std::getenv("LBM_DEEP_HALO");
+        c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(dh && std::atoi(dh) == 0);
         const char* nt = std::getenv("LBM_NT");
         c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
     }
@@ -790,6 +849,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // thousands of workgroups of the interior kernel they are meant to overlap
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* pr = std::getenv("LBM_COMM_PRIORITY");   // A/B: 0 = same priority as the compute stream
+        if (pr && std::atoi(pr) == 0) hi = lo;
         if ((e = hipStreamCreateWithPriority(&c->s_comm, hipStreamNonBlocking, hi)) != hipSuccess) return cleanup("hipStreamCreate");
     }
     if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
@@ -839,7 +900,7 @@ int lbm_init_equilibrium(lbm_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->p.device));
     int rc = sync_all(c);
     if (rc) return rc;
-    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_pending = false;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
         hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
@@ -858,7 +919,7 @@ int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
     if (rc) return rc;
     rc = host_to_stage(c, fin_host, host_dtype, Q * c->batch);   // [B][9][nx][ny] is B * 9 planes
     if (rc) return rc;
-    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_pending = false;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
         hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
@@ -1022,6 +1083,7 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     c->nranks = nranks;
     c->rank = rank;
     c->halo_pending = false;
+    c->deep_pending = false;
     return LBM_OK;
 }
 
@@ -1039,6 +1101,7 @@ int lbm_comm_loopback(lbm_ctx* c) {
     c->rank = 0;
     c->loopback = true;
     c->halo_pending = false;
+    c->deep_pending = false;
     return LBM_OK;
 }
 

@@ -533,6 +533,29 @@ def test_fast_arithmetic_agrees_with_oracle_to_rounding(kernel, turb, monkeypatc
             assert np.abs(u32 - a32.u).max() / 0.08 < 2e-4
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fast_arithmetic_is_the_same_in_every_kernel(dtype, monkeypatch):
+    """The factored operator spells its fused multiply-adds out, so the one-cell-per-thread kernel, the vector kernel and
+    the multi-step kernels (any steps per launch), slabs or not, all give the same bits -- as the strict form does."""
+    nx, ny, steps = 132, 99, 37
+    with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=dtype, kernel="generic", arith="fast") as g:
+        g.step(steps)
+        ref = g.get_fields(want_fin=True)
+    for kernel, tbs in (("vec", ""), ("tb", "2"), ("tb", "3"), ("tb", "4"), ("tb", "5")):
+        if tbs:
+            monkeypatch.setenv("LBM_TB_STEPS", tbs)
+        with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=dtype, kernel=kernel, arith="fast") as s:
+            s.step(steps)
+            assert all(np.array_equal(x, y) for x, y in zip(ref, s.get_fields(want_fin=True))), (kernel, tbs)
+    slabs = [CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=dtype, arith="fast", rows=r) for r in partition_rows(ny, 3)]
+    LocalSlabs(slabs).step(steps)
+    u = np.zeros_like(ref[0]); rho = np.zeros_like(ref[1]); fin = np.zeros_like(ref[2])
+    for s in slabs:
+        s.get_fields(u=u, rho=rho, fin=fin)
+        s.close()
+    assert np.array_equal(fin, ref[2]) and np.array_equal(u, ref[0]) and np.array_equal(rho, ref[1])
+
+
 def test_fast_arithmetic_config_c1_centrelines():
     """north_star's tolerance on the fast path: 128 x 128, Re = 100, fp64, 1000 steps (config C1 with the MRT operator):
     centreline velocities within 1e-6 relative of the oracle's; collisions conserve mass as exactly as the strict form."""
@@ -597,17 +620,24 @@ def test_rccl_single_rank_communicator_is_transparent():
         assert all(np.array_equal(x, y) for x, y in zip(a.get_fields(want_fin=True), b.get_fields(want_fin=True)))
 
 
-@pytest.mark.parametrize("dtype,coll,turb", [(np.float32, "MRT", 0), (np.float64, "SRT", 1)])
-def test_rccl_exchange_path_in_loopback(dtype, coll, turb):
+@pytest.mark.parametrize("deep", ["1", "0"])
+@pytest.mark.parametrize("kernel,layout", [("auto", "rows"), ("tb", "rows"), ("tb", "planes")])
+@pytest.mark.parametrize("dtype,coll,turb,arith", [(np.float32, "MRT", 0, "strict"), (np.float64, "SRT", 1, "strict"),
+                                                   (np.float32, "MRT", 0, "fast"), (np.float32, "TRT", 1, "strict")])
+def test_rccl_exchange_path_in_loopback(dtype, coll, turb, arith, kernel, layout, deep, monkeypatch):
     """lbm_step's in-library exchange (edge/interior split, comm stream, events, ncclSend/ncclRecv straight from
     lattice rows into ghost rows) on ONE GPU: a middle slab exchanges with itself (periodic in y).  Expected
-    result: the same slab stepped with the externally driven API and the same wrap done through host buffers."""
+    result: the same slab stepped with the externally driven API and the same wrap done through host buffers.
+    kernel='tb': multi-step launches between slabs -- one deep exchange per launch (LBM_DEEP_HALO=1, the default: the frame
+    passes recompute a shrinking band of the neighbour's rows) or one one-row exchange per pass (LBM_DEEP_HALO=0)."""
     from latticeboltzmannsimulations_amd.slab import LOW, HIGH
-    nx, NY, rows, steps = 512, 300, (100, 96), 25
-    a = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb)
-    b = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb)
+    monkeypatch.setenv("LBM_DEEP_HALO", deep)
+    nx, NY, rows, steps = 512, 300, (100, 96), 31
+    a = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel=kernel, layout=layout, arith=arith)
+    b = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel="generic", layout=layout, arith=arith)
     a.comm_loopback()
-    a.step(steps)
+    a.step(steps - 8)
+    a.step(8)                      # a second call: starts with the halo of the first call's last (single) step
     up = np.empty(b.halo_elems(), dtype=dtype); down = np.empty(b.halo_elems(), dtype=dtype)
     for _ in range(steps):
         b.step_edges(); b.step_interior(); b.step_finish()
