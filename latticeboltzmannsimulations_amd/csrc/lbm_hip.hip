@@ -247,7 +247,7 @@ struct lbm_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
-    bool deep_pending = false;  // ... and it was a deep one (tb_steps complete rows per side, for the next multi-step)
+    int deep_rows = 0;          // ... and it was a deep one: this many complete rows per side (for the next multi-step)
     bool deep_halo = false;     // multi-steps between slabs exchange once per launch (MRT_GPU semantics; LBM_DEEP_HALO=0 disables)
     bool loopback = false;      // diagnostic: 1-rank communicator, the slab exchanges halos with itself
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
@@ -411,13 +411,13 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0
     return LBM_OK;
 }
 
-// c->tb_steps steps on the deep interior, lat[from] -> lat[to].
-int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
+// `steps` steps on the deep interior, lat[from] -> lat[to] (c->tb_steps, or fewer for the last launch of a call).
+int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
         const int F = c->tb_f, xe = c->geo.nx - F, ye = c->geo.ny - F;
-        if (c->tb_steps >= 3) {
+        if (steps >= 3) {
             constexpr int V = 16 / (int)sizeof(R);
             auto go = [&](auto steps, auto wide) {
                 constexpr int S = decltype(steps)::value;
@@ -428,12 +428,12 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s) {
                                    (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty);
             };
             if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
-                if (c->tb_steps == 4) {
+                if (steps == 4) {
                     if (c->tb3_wide) go(std::integral_constant<int, 4>{}, std::true_type{});
                     else go(std::integral_constant<int, 4>{}, std::false_type{});
                     return;
                 }
-                if (c->tb_steps == 5) {
+                if (steps == 5) {
                     if (c->tb3_wide) go(std::integral_constant<int, 5>{}, std::true_type{});
                     else go(std::integral_constant<int, 5>{}, std::false_type{});
                     return;
@@ -596,7 +596,7 @@ int single_step(lbm_ctx* c, bool* comm_used) {
         rc = enqueue_exchange(c, c->cur);
         if (rc) return rc;
         c->halo_pending = true;
-        c->deep_pending = false;
+        c->deep_rows = 0;
         *comm_used = true;
         return LBM_OK;
     }
@@ -615,15 +615,15 @@ int single_step(lbm_ctx* c, bool* comm_used) {
 // (MRT_GPU semantics) the row strips of pass i start S - i rows inside the neighbour's rows received before the unit, and the
 // only exchange is the one for the next unit; otherwise every pass is followed by a one-row exchange.  (Running row and
 // column strips as separate launches on separate streams was measured and lost 8 %: profiles/r01_logs/perf31.log, perf35.log.)
-int multi_step(lbm_ctx* c, bool* comm_used, bool next_is_multi) {
+int multi_step(lbm_ctx* c, bool* comm_used, int S, int S_next) {
     const bool multi = c->nranks > 1 || c->loopback;
     const bool deep = multi && c->deep_halo;
-    const int S = c->tb_steps, a = c->cur, b = c->cur ^ 1;
+    const int a = c->cur, b = c->cur ^ 1;   // S: steps of this unit; S_next: of the next one if it is a multi-step too (else 0)
     HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
     HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // this unit's tile kernel needs the previous unit's frame
     int rc;
     int from = a;
-    if (multi && (deep ? !c->deep_pending : !c->halo_pending)) {
+    if (multi && (deep ? c->deep_rows < S : !c->halo_pending)) {
         rc = deep ? enqueue_deep_exchange(c, a, S) : enqueue_exchange(c, a);
         if (rc) return rc;
     }
@@ -640,21 +640,31 @@ int multi_step(lbm_ctx* c, bool* comm_used, bool next_is_multi) {
         from = to;
     }
     HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
-    rc = launch_deep(c, a, b, c->s_compute);
+    rc = launch_deep(c, a, b, c->s_compute, S);
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
     c->cur ^= 1;
     c->raw[c->cur] = 0;
     c->nsteps += S;
     if (multi) {   // the halo of the next unit, behind the last row strips and beside this unit's tile kernel
-        const bool deep_next = deep && next_is_multi;
-        rc = deep_next ? enqueue_deep_exchange(c, c->cur, S) : enqueue_exchange(c, c->cur);
+        const bool deep_next = deep && S_next > 0;
+        rc = deep_next ? enqueue_deep_exchange(c, c->cur, S_next) : enqueue_exchange(c, c->cur);
         if (rc) return rc;
         c->halo_pending = true;
-        c->deep_pending = deep_next;
+        c->deep_rows = deep_next ? S_next : 0;
     }
     *comm_used = true;
     return LBM_OK;
+}
+
+// Steps of the next unit when `left` steps remain.  The first step after an upload reads raw populations, and the LAST step
+// of a call is always a single step (lbm_get_fields needs the lattice of the step before the last for the one-step lag of
+// u / rho); what remains before it goes into one shorter launch of the in-place kernel (same frame width) if that is >= 3 steps.
+int unit_steps(const lbm_ctx* c, int left, bool raw) {
+    if (!c->use_tb || raw || left < 1) return left < 1 ? 0 : 1;
+    if (left >= c->tb_steps + 1) return c->tb_steps;
+    if (c->tb_steps >= 3 && left - 1 >= 3) return left - 1;
+    return 1;
 }
 
 int step_many(lbm_ctx* c, int nsteps) {
@@ -663,15 +673,16 @@ int step_many(lbm_ctx* c, int nsteps) {
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier calls)
     int left = nsteps;
     while (left > 0) {
-        // The first step after an upload reads raw populations, and the LAST step of a call is always a single step:
-        // lbm_get_fields needs the lattice of the step before the last for the one-step lag of u / rho.
+        const int S = unit_steps(c, left, c->raw[c->cur] != 0);
         int rc;
-        if (c->use_tb && !c->raw[c->cur] && left >= c->tb_steps + 1) {
-            rc = multi_step(c, &comm_used, left - c->tb_steps >= c->tb_steps + 1);
-            left -= c->tb_steps;
+        if (S > 1) {
+            const int S_next = unit_steps(c, left - S, false);
+            rc = multi_step(c, &comm_used, S, S_next > 1 ? S_next : 0);
+        } else {
+            rc = single_step(c, &comm_used);
         }
-        else { rc = single_step(c, &comm_used); left -= 1; }
         if (rc) return rc;
+        left -= S;
     }
     if (comm_used) {   // later single-stream work (export, timing event, split-step API) must see the s_comm results
         HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
@@ -900,7 +911,7 @@ int lbm_init_equilibrium(lbm_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->p.device));
     int rc = sync_all(c);
     if (rc) return rc;
-    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_pending = false;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_rows = 0;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
         hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
@@ -919,7 +930,7 @@ int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
     if (rc) return rc;
     rc = host_to_stage(c, fin_host, host_dtype, Q * c->batch);   // [B][9][nx][ny] is B * 9 planes
     if (rc) return rc;
-    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_pending = false;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_rows = 0;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
         hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
@@ -1083,7 +1094,7 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     c->nranks = nranks;
     c->rank = rank;
     c->halo_pending = false;
-    c->deep_pending = false;
+    c->deep_rows = 0;
     return LBM_OK;
 }
 
@@ -1101,7 +1112,7 @@ int lbm_comm_loopback(lbm_ctx* c) {
     c->rank = 0;
     c->loopback = true;
     c->halo_pending = false;
-    c->deep_pending = false;
+    c->deep_rows = 0;
     return LBM_OK;
 }
 
