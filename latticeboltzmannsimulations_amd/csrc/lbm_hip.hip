@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: RCCL is bound lazily with dlopen (see rccl_api)
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -101,19 +102,83 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
     update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
 }
 
+// All S frame passes of a multi-step in ONE launch.  The frame (width F) is cut into rectangles: segments of FR_L columns of the
+// top and bottom row strips, segments of FR_L rows of the left and right column strips; one workgroup per rectangle.  Pass i
+// (margin m = S - i) computes the rectangle grown by m cells in x and y (clipped to the lattice; the rows of a slab interface
+// grow m rows into the neighbour's rows of the deep halo), all of it inside the frame of width F + m, from the output of pass
+// i - 1 -- every cell a workgroup reads it has written itself one pass earlier, so workgroups never wait for each other; where
+// grown rectangles overlap, both workgroups write the same bits.  Each pass has its own scratch lattice (a ping-pong pair would
+// let a fast workgroup overwrite cells a slow neighbour still reads); the last pass writes lat[b].  Same per-cell operations as
+// S launches of k_step_frame.
+constexpr int FR_L = 64;
+template <typename R>
+struct FramePtrs {
+    const R* src;    // state n
+    R* pass[5];      // output of pass 1 .. S (pass[S - 1] = the destination lattice)
+};
+
+template <typename R>
+__device__ __forceinline__ R* pass_ptr(const FramePtrs<R>& fp, int j) {   // (selects, not an indexed load: no private-memory copy)
+    return j == 0 ? fp.pass[0] : j == 1 ? fp.pass[1] : j == 2 ? fp.pass[2] : j == 3 ? fp.pass[3] : fp.pass[4];
+}
+
+template <typename R, int COLL, int SEM, bool TURB, int NT>
+__device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long boff, const Geo& geo, const Relax<R>& w, int F, int S,
+                                             int nsegx, int nsegy, int lo, int hi, int b) {
+    int x0, x1, y0, y1;   // owned rectangle [x0, x1) x [y0, y1)
+    if (b < 2 * nsegx) {
+        const int seg = b % nsegx;
+        x0 = seg * FR_L; x1 = min(geo.nx, x0 + FR_L);
+        y0 = b < nsegx ? 0 : geo.ny - F; y1 = y0 + F;
+    } else {
+        b -= 2 * nsegx;
+        const int seg = b % nsegy;
+        y0 = F + seg * FR_L; y1 = min(geo.ny - F, y0 + FR_L);
+        x0 = b < nsegy ? 0 : geo.nx - F; x1 = x0 + F;
+    }
+    for (int i = 1; i <= S; ++i) {
+        const int m = S - i;
+        const int xa = max(0, x0 - m), xb = min(geo.nx, x1 + m);
+        const int ya = max(lo ? -m : 0, y0 - m), yb = min(geo.ny + (hi ? m : 0), y1 + m);
+        const int wx = xb - xa, n = wx * (yb - ya);
+        const R* src = (i == 1 ? fp.src : pass_ptr(fp, i - 2)) + boff;
+        R* dst = pass_ptr(fp, i - 1) + boff;
+        for (int t = threadIdx.x; t < n; t += NT) update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, 0, xa + t % wx, ya + t / wx);
+        __syncthreads();   // workgroup-scope release / acquire: the next pass reads what this one wrote (global memory)
+    }
+}
+
+template <typename R, int COLL, int SEM, bool TURB>
+__global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, Relax<R> w, Batch<R> bt, int F, int S, int nsegx, int nsegy,
+                                                     int lo, int hi) {
+    long long boff = 0;
+    if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
+    frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x);
+}
+
 // S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS.  The
 // occupancy floor of 4 waves per SIMD (<= 128 VGPRs) keeps two workgroups on a CU: the MRT / TRT + Smagorinsky variants would
 // otherwise take 132 and run one (perf22.log vs perf23.log: fp32 MRT turb 96 -> 115 GLUPS).  WIDE: region 32 vectors x 16 rows;
 // otherwise 16 vectors x 32 rows (less rim work, shorter row segments).  The tile is the region minus the rim: V cells
 // left and right, S - 1 rows above and below.  F = frame width (4; 8 for S = 4 in fp32).
-template <typename R, int COLL, int S, bool WIDE, bool TURB>
+template <typename R, int COLL, int SEM, int S, bool WIDE, bool TURB>
 __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
-                                                    Batch<R> bt, int F, int xe, int ye, int ntx, int ntiles) {
-    LBM_BATCH_SELECT(blockIdx.y)
+                                                    Batch<R> bt, int F, int xe, int ye, int ntx, int ntiles, FramePtrs<R> fp, int nframe,
+                                                    int nsegx, int nsegy) {
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
     constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
     __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
-    int b = blockIdx.x;                                                     // read one element past their row
+    if ((int)blockIdx.x < nframe) {                                         // read one element past their row
+        // A lone lattice: the first nframe workgroups of the launch do the S frame passes (frame_passes), the rest the tiles --
+        // one launch per S steps and no cross-stream dependency (between slabs the frame stays a launch of its own on the
+        // communication stream: nframe = 0).  The frame workgroups run S dependent passes and take the longest: they go first.
+        long long boff = 0;
+        if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
+        frame_passes<R, COLL, SEM, TURB, 512>(fp, boff, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x);
+        return;
+    }
+    LBM_BATCH_SELECT(blockIdx.y)
+    int b = blockIdx.x - nframe;
     const int per = ntiles >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
     update_tile_inplace<R, COLL, V, TX, TY, S, TURB>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
@@ -236,7 +301,7 @@ struct lbm_ctx {
     lbm_params p{};
     int es = 0;  // element size
     Geo geo{};
-    void* lat[4] = {nullptr, nullptr, nullptr, nullptr};   // [0], [1]: the two lattices; [2], [3]: frame scratch of the multi-step
+    void* lat[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0], [1]: the two lattices; [2] ..: frame scratch of the multi-step
     int raw[2] = {1, 1};
     int cur = 0;  // lat[cur] is the source of the next step
     long long nsteps = 0;
@@ -247,6 +312,7 @@ struct lbm_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
+ bool frame_fused = true;    // all frame passes of a multi-step in one launch (LBM_FRAME_FUSED=0: one launch per pass)
     int deep_rows = 0;          // ... and it was a deep one: this many complete rows per side (for the next multi-step)
     bool deep_halo = false;     // multi-steps between slabs exchange once per launch (MRT_GPU semantics; LBM_DEEP_HALO=0 disables)
     bool loopback = false;      // diagnostic: 1-rank communicator, the slab exchanges halos with itself
@@ -411,8 +477,25 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0
     return LBM_OK;
 }
 
+// All S frame passes lat[from] -> lat[to] in one launch (k_frame_multi); lo / hi: the slab has a neighbour below row 0 / above
+// row ny - 1 whose rows lie in the ghost rows (deep halo).
+int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool lo, bool hi) {
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
+        FramePtrs<R> fp;
+        fp.src = (const R*)c->lat[from];
+        for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+        const int F = c->tb_f, nsegx = (c->geo.nx + FR_L - 1) / FR_L, nsegy = (c->geo.ny - 2 * F + FR_L - 1) / FR_L;
+        hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
+                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 : 0, hi ? 1 : 0);
+    });
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
 // `steps` steps on the deep interior, lat[from] -> lat[to] (c->tb_steps, or fewer for the last launch of a call).
-int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps) {
+int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool with_frame = false) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
@@ -424,8 +507,14 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps) {
                 constexpr bool WIDE = decltype(wide)::value;
                 constexpr int PVC = WIDE ? 32 : 16, TX = (PVC - 2) * V, TY = 512 / PVC - 2 * (S - 1);
                 const int ntx = (xe - F + TX - 1) / TX, nty = (ye - F + TY - 1) / TY;
-                hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, S, WIDE, VT::TURB>), dim3(ntx * nty, c->batch), dim3(512), 0, s, (const R*)c->lat[from],
-                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty);
+                FramePtrs<R> fp;
+                fp.src = (const R*)c->lat[from];
+                for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+                const int nsegx = (c->geo.nx + FR_L - 1) / FR_L, nsegy = (c->geo.ny - 2 * F + FR_L - 1) / FR_L;
+                const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
+                hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, VT::SEM, S, WIDE, VT::TURB>), dim3(nframe + ntx * nty, c->batch), dim3(512), 0, s,
+                                   (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty,
+                                   fp, nframe, nsegx, nsegy);
             };
             if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
                 if (steps == 4) {
@@ -617,6 +706,16 @@ int single_step(lbm_ctx* c, bool* comm_used) {
 // column strips as separate launches on separate streams was measured and lost 8 %: profiles/r01_logs/perf31.log, perf35.log.)
 int multi_step(lbm_ctx* c, bool* comm_used, int S, int S_next) {
     const bool multi = c->nranks > 1 || c->loopback;
+    if (!multi && c->frame_fused && S >= 3) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
+        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // (frame launches of an earlier unit, if any)
+        int rc = launch_deep(c, c->cur, c->cur ^ 1, c->s_compute, S, true);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+        c->cur ^= 1;
+        c->raw[c->cur] = 0;
+        c->nsteps += S;
+        return LBM_OK;
+    }
     const bool deep = multi && c->deep_halo;
     const int a = c->cur, b = c->cur ^ 1;   // S: steps of this unit; S_next: of the next one if it is a multi-step too (else 0)
     HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
@@ -628,6 +727,10 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, int S_next) {
         if (rc) return rc;
     }
     const bool has_lo = multi && (c->loopback || c->rank > 0), has_hi = multi && (c->loopback || c->rank < c->nranks - 1);
+    if (c->frame_fused && S >= 3 && (!multi || deep)) {
+        rc = launch_frame_multi(c, a, b, S, c->s_comm, deep && has_lo, deep && has_hi);
+        if (rc) return rc;
+    } else
     for (int i = 1; i <= S; ++i) {
         const int to = i == S ? b : 2 + ((i - 1) & 1);
         const int ext = deep ? S - i : 0;
@@ -849,6 +952,11 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  LBM_TB3_WIDE=1 selects 30 x 12.
         const char* shp = std::getenv("LBM_TB3_WIDE");
         c->tb3_wide = shp && std::atoi(shp) != 0;
+        const char* ff = std::getenv("LBM_FRAME_FUSED");
+        // measured (profiles/r01_logs/perf37.log, perf38.log): one launch per unit instead of S + 1 and no cross-stream dependency:
+        // 4096^2 fp32 278 -> 294 GLUPS, 1024^2 fp64 67 -> 91, 1024^2 fp32 96 -> 135; a batch of 64 x 384^2 loses 5 % (its many
+        // short frame workgroups do better as separate small launches), so batches keep one launch per pass
+        c->frame_fused = !(ff && std::atoi(ff) == 0) && c->batch == 1;
         const char* dh = std::getenv("LBM_DEEP_HALO");
         c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(dh && std::atoi(dh) == 0);
         const char* nt = std::getenv("LBM_NT");
@@ -869,7 +977,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
-    for (int i = 0; i < (c->use_tb ? (c->tb_steps == 2 ? 3 : 4) : 2); ++i) {   // frame passes ping-pong between lat[2], lat[3]
+    // scratch lattices of the frame passes: one per pass but the last (the fused frame kernel), at least the ping-pong pair
+    for (int i = 0; i < (c->use_tb ? (c->tb_steps == 2 ? 3 : 2 + std::max(2, c->tb_steps - 1)) : 2); ++i) {
         if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
         // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
         if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
@@ -890,7 +999,7 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->s_compute) (void)hipStreamSynchronize(c->s_compute);
     if (c->s_comm) (void)hipStreamSynchronize(c->s_comm);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if (c->lat[i]) (void)hipFree(c->lat[i]);
     if (c->stage) (void)hipFree(c->stage);
     if (c->relax_dev) (void)hipFree(c->relax_dev);
