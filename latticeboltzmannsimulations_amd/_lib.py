@@ -23,6 +23,7 @@ LBM_KERNEL_AUTO, LBM_KERNEL_GENERIC, LBM_KERNEL_VEC, LBM_KERNEL_TB = 0, 1, 2, 3
 LBM_LAYOUT_AUTO, LBM_LAYOUT_PLANES, LBM_LAYOUT_ROWS = 0, 1, 2
 LBM_SIDE_LOW, LBM_SIDE_HIGH = 0, 1
 LBM_ARITH_STRICT, LBM_ARITH_FAST = 0, 1
+ABI_VERSION = 2        # = LBM_ABI_VERSION of include/lbm.h (tests/test_abi.py keeps them equal)
 
 
 class lbm_params(ctypes.Structure):
@@ -117,7 +118,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if an exported symbol is missing
             f.restype, f.argtypes = res, args
-        if L.lbm_abi_version() != 2:
+        if L.lbm_abi_version() != ABI_VERSION:
             raise RuntimeError("liblbm_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for n in declared_functions():
         assert hasattr(L, n), f"{n} declared in include/lbm.h but not exported"
-    assert _lib.lib().lbm_abi_version() == 2
+    hdr = int(re.search(r"#define LBM_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "lbm.h")).read()).group(1))
+    assert _lib.lib().lbm_abi_version() == hdr == _lib.ABI_VERSION
 
 
 def test_library_has_no_static_rccl_dependency():
