@@ -67,8 +67,9 @@ typedef struct lbm_params {
                             leading [B] axis.  Not combinable with slabs. */
     int32_t arith;       /* LBM_ARITH_STRICT (0, default): every operation in the reference's order, results bit-identical to
                             the CPU restatement in oracle/.  LBM_ARITH_FAST: the MRT operator in an algebraically identical
-                            factored form (about half the arithmetic); results agree to rounding, not bit for bit.  SRT and
-                            TRT are unaffected. */
+                            factored form with fused multiply-adds (about half the arithmetic); in fp32 also u = j * rcp(rho)
+                            and the Smagorinsky closure's divisions / square root by the 1-ulp hardware instructions.
+                            Results agree with the strict form to rounding, not bit for bit. */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */
     double omega;        /* = omegap = omega_nu, MRT_GPU.py:65 */
     double omegam;       /* TRT, MRT_GPU.py:80 */

@@ -21,8 +21,12 @@ __host__ __device__ constexpr int cyk(int k) { return k == 2 || k == 5 || k == 6
 
 enum { SEM_PY = 0, SEM_GPU = 1 };
 enum { C_SRT = 0, C_TRT = 1, C_MRT = 2,
-       C_MRT_FAST = 3 };   // the MRT operator in factored form (lbm_params.arith = LBM_ARITH_FAST): not the reference's operation order
+       // lbm_params.arith = LBM_ARITH_FAST: not the reference's operation order / rounding --
+       C_MRT_FAST = 3,     // the MRT operator in factored form with fused multiply-adds
+       C_SRT_FAST = 4,     // SRT / TRT as in the strict form, but (fp32) u = j * rcp(rho) and the closure's divisions and
+       C_TRT_FAST = 5 };   // square root by the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 instead of the IEEE sequences
 constexpr bool coll_is_mrt(int c) { return c == C_MRT || c == C_MRT_FAST; }
+constexpr bool coll_is_fast(int c) { return c >= C_MRT_FAST; }
 
 template <typename R>
 struct Relax {  // a2: MRT_GPU.py:63-93
@@ -76,6 +80,19 @@ template <typename R>
 __device__ __forceinline__ R weight(int k) {
     return k == 0 ? (R)(4.0 / 9.0) : (k < 5 ? (R)(1.0 / 9.0) : (R)(1.0 / 36.));
 }
+// a / b and sqrt: IEEE-exact, or (FAST, fp32 only) by v_rcp_f32 / v_sqrt_f32 (1 ulp) -- the same instruction per lane in the
+// scalar and the packed form, so every kernel variant still produces the same bits
+template <bool FAST> __device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ double div_(double a, double b) { return a / b; }
+template <bool FAST> __device__ __forceinline__ f32x2 div_(f32x2 a, f32x2 b) {
+    return FAST ? a * f32x2{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)} : a / b;
+}
+template <bool FAST> __device__ __forceinline__ float sqrt_(float a) { return FAST ? __builtin_amdgcn_sqrtf(a) : sqrtf(a); }
+template <bool FAST> __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
+template <bool FAST> __device__ __forceinline__ f32x2 sqrt_(f32x2 a) {
+    return FAST ? f32x2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)} : f32x2{sqrtf(a.x), sqrtf(a.y)};
+}
+
 template <typename T>
 __device__ __forceinline__ void equ(T rho, T ux, T uy, T (&feq)[Q]) {
     typedef typename ScalarOf<T>::type S;
@@ -90,11 +107,11 @@ __device__ __forceinline__ void equ(T rho, T ux, T uy, T (&feq)[Q]) {
 
 // a4 + a5: moments with the macroscopic wall overrides (MRT.py:292,320-321,337,341-342;
 // MRT_GPU.py:389-405).  rho_sum is the plain sum (used by nothing but kept for clarity).
-template <typename R>
+template <typename R, bool FAST = false>
 __device__ __forceinline__ void macros(const R (&f)[Q], int x, int gy, int X, int Y, R uLB, R& rho, R& ux, R& uy) {
     rho = ((((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7]) + f[8]);
-    ux = (((((f[1] - f[3]) + f[5]) - f[6]) - f[7]) + f[8]) / rho;
-    uy = (((((f[2] - f[4]) + f[5]) + f[6]) - f[7]) - f[8]) / rho;
+    ux = div_<FAST>((((((f[1] - f[3]) + f[5]) - f[6]) - f[7]) + f[8]), rho);
+    uy = div_<FAST>((((((f[2] - f[4]) + f[5]) + f[6]) - f[7]) - f[8]), rho);
     if (x == 0 || x == X - 1 || gy == Y - 1) { ux = (R)0; uy = (R)0; }
     if (gy == 0) {
         rho = ((f[0] + f[1]) + f[3]) + (R)2. * ((f[2] + f[5]) + f[6]);
@@ -116,10 +133,10 @@ __device__ __forceinline__ void collide(const T (&f)[Q], T rho, const T (&feq)[Q
                                         const Relax<typename ScalarOf<T>::type>& w, T w_nu, T (&out)[Q]) {
     // w_nu: the viscous rate of each cell (w.w_nu, or the Smagorinsky value); the other rates are lattice-wide scalars
     typedef typename ScalarOf<T>::type R;
-    if (COLL == C_SRT) {
+    if (COLL == C_SRT || COLL == C_SRT_FAST) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) out[k] = f[k] - w_nu * (f[k] - feq[k]);
-    } else if (COLL == C_TRT) {
+    } else if (COLL == C_TRT || COLL == C_TRT_FAST) {
         T fp[Q], fm[Q], ep[Q], em[Q];
         constexpr int pa[4] = {2, 5, 6, 1}, pb[4] = {4, 7, 8, 3};
 #pragma unroll
@@ -223,21 +240,18 @@ template <typename T>
 __device__ __forceinline__ T diag_flux(const T (&f)[Q]) {   // product = cx cy f_k + product, k = 0..8
     return -f[8] + (f[7] + (-f[6] + f[5]));
 }
-__device__ __forceinline__ float real_sqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ double real_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ f32x2 real_sqrt(f32x2 x) { return f32x2{sqrtf(x.x), sqrtf(x.y)}; }
 __device__ __forceinline__ float real_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double real_abs(double x) { return fabs(x); }
 __device__ __forceinline__ f32x2 real_abs(f32x2 x) { return f32x2{fabsf(x.x), fabsf(x.y)}; }
 
 // T: scalar real or f32x2; the result is the per-cell relaxation rate (a T, not a scalar)
-template <typename T>
+template <typename T, bool FAST = false>
 __device__ __forceinline__ T smagorinsky_omega(const T (&f)[Q], T qeq_prev, T rho_prev, typename ScalarOf<T>::type omega) {
     typedef typename ScalarOf<T>::type R;
     const R tau0 = (R)1.0 / omega;
     const T q = diag_flux<T>(f) - qeq_prev;
-    const T tau = (R)0.5 * (tau0 + real_sqrt(tau0 * tau0 + (((R)(18 * 1.4142) * (R)0.025) * real_abs(q)) / rho_prev));
-    return (R)1.0 / tau;
+    const T tau = (R)0.5 * (tau0 + sqrt_<FAST>(tau0 * tau0 + div_<FAST>(((R)(18 * 1.4142) * (R)0.025) * real_abs(q), rho_prev)));
+    return div_<FAST>(T((R)1.0), tau);
 }
 
 // a8: wall rules on the populations of ONE perimeter cell, given the equilibrium of the
@@ -346,8 +360,8 @@ __device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __rest
     const long long me = geo.at(x, y);
     const Relax<R>& w = w0;
     R w_nu = w0.w_nu;
-    if (TURB) w_nu = smagorinsky_omega<R>(g, src[K_QEQ * geo.plane + me], src[K_RHO * geo.plane + me], w0.w_nu);
-    macros<R>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
+    if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, src[K_QEQ * geo.plane + me], src[K_RHO * geo.plane + me], w0.w_nu);
+    macros<R, coll_is_fast(COLL)>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
     equ<R>(rho, ux, uy, fe);
     collide<R, COLL>(g, rho, fe, w, w_nu, out);
     if (TURB) {
@@ -430,11 +444,11 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
             if (right) { g[3] = (R)0 + g[1]; g[6] = (R)0 + g[8]; g[7] = (R)0 + g[5]; }
         }
         R w_nu = w0.w_nu;
-        if (TURB) w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
+        if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, hq[c], hr[c], w0.w_nu);
         R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
         if (!coll_is_mrt(COLL) || TURB) {   // the plain MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
-            R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
-            R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
+            R ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
+            R uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
             if (left || right) { ux = (R)0; uy = (R)0; }
             equ<R>(rho, ux, uy, fe);
         }
@@ -478,11 +492,11 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = p == 0 ? in[k].xy : in[k].zw;
             f32x2 w_nu = (f32x2)(w0.w_nu);
-            if (TURB) w_nu = smagorinsky_omega<f32x2>(g, p == 0 ? hq.xy : hq.zw, p == 0 ? hr.xy : hr.zw, w0.w_nu);
+            if (TURB) w_nu = smagorinsky_omega<f32x2, coll_is_fast(COLL)>(g, p == 0 ? hq.xy : hq.zw, p == 0 ? hr.xy : hr.zw, w0.w_nu);
             const f32x2 rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
             if (!coll_is_mrt(COLL) || TURB) {
-                const f32x2 ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
-                const f32x2 uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
+                const f32x2 ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
+                const f32x2 uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
                 equ<f32x2>(rho, ux, uy, fe);
             }
             collide<f32x2, COLL>(g, rho, fe, w0, w_nu, out);
@@ -504,11 +518,11 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = in[k][c];
             R w_nu = w0.w_nu;
-            if (TURB) w_nu = smagorinsky_omega<R>(g, hq[c], hr[c], w0.w_nu);
+            if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, hq[c], hr[c], w0.w_nu);
             const R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
             if (!coll_is_mrt(COLL) || TURB) {
-                const R ux = (((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]) / rho;
-                const R uy = (((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]) / rho;
+                const R ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
+                const R uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
                 equ<R>(rho, ux, uy, fe);
             }
             collide<R, COLL>(g, rho, fe, w0, w_nu, out);

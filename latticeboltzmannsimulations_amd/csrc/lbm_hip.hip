@@ -425,8 +425,14 @@ void dispatch(const lbm_params& p, F&& f) {
     };
     auto by_coll = [&](auto real) {
         switch (p.collision) {
-            case LBM_SRT: by_sem(real, std::integral_constant<int, C_SRT>{}); break;
-            case LBM_TRT: by_sem(real, std::integral_constant<int, C_TRT>{}); break;
+            case LBM_SRT:
+                if (p.arith == LBM_ARITH_FAST) by_sem(real, std::integral_constant<int, C_SRT_FAST>{});
+                else by_sem(real, std::integral_constant<int, C_SRT>{});
+                break;
+            case LBM_TRT:
+                if (p.arith == LBM_ARITH_FAST) by_sem(real, std::integral_constant<int, C_TRT_FAST>{});
+                else by_sem(real, std::integral_constant<int, C_TRT>{});
+                break;
             default:
                 if (p.arith == LBM_ARITH_FAST) by_sem(real, std::integral_constant<int, C_MRT_FAST>{});
                 else by_sem(real, std::integral_constant<int, C_MRT>{});
@@ -941,10 +947,12 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // with the closure (perf23.log, 4096^2 fp32, S = 2 / 3 / 4): SRT 108 / 150 / 162, TRT 110 / 145 / 124 (S = 4 spills
         // under the 128-register occupancy floor), MRT 109 / 111 / 115; fp64 SRT 57 / 81 / 83, MRT 61 / 72 / 73
         const bool trt_turb = p->turb && p->collision == LBM_TRT;
-        // factored MRT operator (arith = FAST; perf28.log, perf29.log): at S = 5 the strict form is arithmetic-bound (209 GLUPS,
-        // as at S = 4), the factored one is not: S = 3 / 4 / 5 = 176 / 217 / 252-261 GLUPS
-        const bool fast_mrt = p->arith == LBM_ARITH_FAST && p->collision == LBM_MRT;
-        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 && !trt_turb ? (fast_mrt ? 5 : 4) : 3);
+        // arith = FAST (perf28.log, perf29.log, perf40.log): at S = 5 the strict MRT form is arithmetic-bound (209 GLUPS, as at
+        // S = 4), the factored one is not: S = 3 / 4 / 5 = 184 / 227 / 277 GLUPS; SRT 189 / 237 / 250, with the closure 152 / 188 /
+        // 217; MRT + closure 150 / 187 / 202; TRT 185 / 210 / 210, with the closure 152 / 163 / 156
+        const bool fast = p->arith == LBM_ARITH_FAST;
+        const int want32 = fast ? (p->collision == LBM_TRT ? 4 : 5) : (trt_turb ? 3 : 4);
+        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 ? want32 : 3);
         const bool deep_ok = p->dtype == LBM_F32 && p->nx >= 64 && p->ny_local >= 64;
         c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
         c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width

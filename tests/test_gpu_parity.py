@@ -556,6 +556,34 @@ def test_fast_arithmetic_is_the_same_in_every_kernel(dtype, monkeypatch):
     assert np.array_equal(fin, ref[2]) and np.array_equal(u, ref[0]) and np.array_equal(rho, ref[1])
 
 
+@pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
+@pytest.mark.parametrize("turb", [0, 1])
+def test_fast_arithmetic_srt_trt_and_closure(coll, turb, monkeypatch):
+    """arith='fast' beyond the MRT operator: in fp32 u = j * rcp(rho) and the closure's divisions / square root use the 1-ulp
+    hardware instructions.  Tolerance against the fp32 oracle after 100 steps: 2e-5 on the populations, 2e-4 on u / uLB;
+    fp64 keeps exact divisions (SRT / TRT fast == strict there, bit for bit).  All kernel variants give the same bits."""
+    nx, ny, steps = 132, 99, 100
+    o32 = CavityOracleC(nx, ny, 5000.0, semantics="mrt_gpu", collision=coll, dtype=np.float32, turb=turb).step(steps)
+    ref = None
+    for kernel, tbs in (("generic", ""), ("vec", ""), ("tb", "3"), ("tb", "5")):
+        if tbs:
+            monkeypatch.setenv("LBM_TB_STEPS", tbs)
+        with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=np.float32, turb=turb, kernel=kernel, arith="fast") as s:
+            s.step(steps)
+            got = s.get_fields(want_fin=True)
+        if ref is None:
+            ref = got
+            assert np.abs(got[2] - o32.fin).max() / np.abs(o32.fin).max() < 2e-5
+            assert np.abs(got[0] - o32.u).max() / 0.08 < 2e-4
+        else:
+            assert all(np.array_equal(x, y) for x, y in zip(ref, got)), (kernel, tbs)
+    if coll != "MRT":
+        o64 = CavityOracleC(nx, ny, 5000.0, semantics="mrt_gpu", collision=coll, dtype=np.float64, turb=turb).step(30)
+        with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=np.float64, turb=turb, arith="fast") as d:
+            d.step(30)
+            same(d, o64, "fp64 SRT / TRT: fast == strict")
+
+
 def test_fast_arithmetic_config_c1_centrelines():
     """north_star's tolerance on the fast path: 128 x 128, Re = 100, fp64, 1000 steps (config C1 with the MRT operator):
     centreline velocities within 1e-6 relative of the oracle's; collisions conserve mass as exactly as the strict form."""
