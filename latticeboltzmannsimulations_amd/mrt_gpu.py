@@ -100,7 +100,7 @@ def _dashboard(path, u, rho, It, hist, Re, RT, regime, BC, xsize, ysize, uLB, re
 
 def run_cavity(maxIt=3000000, Re=10000.0, RT="SRT", turb=1, xsize=32 * 5, ysize=32 * 5, uLB=0.08,
                Pinterval=3000, SavePlot=True, SaveVTK=False, project="ldc", OutputFolder="./output",
-               dtype=np.float32, semantics="mrt_gpu", device=0, quiet=False, solver_factory=None):
+               dtype=np.float32, semantics="mrt_gpu", device=0, quiet=False, solver_factory=None, arith="strict"):
     """Run the lid-driven cavity like MRT_GPU.py does; returns a :class:`CavityResult`.
 
     Argument names and defaults are the module constants of MRT_GPU.py:38-58.
@@ -112,7 +112,8 @@ def run_cavity(maxIt=3000000, Re=10000.0, RT="SRT", turb=1, xsize=32 * 5, ysize=
     say("the value of uLB is ", uLB)
     say("xsize value is ", xsize)
     make = CavitySolver if solver_factory is None else solver_factory
-    solver = make(xsize, ysize, Re, RT=RT, uLB=uLB, semantics=semantics, dtype=dtype, turb=turb, device=device)
+    extra = {} if arith == "strict" else {"arith": arith}      # 'fast': see CavitySolver (agrees with 'strict' to rounding)
+    solver = make(xsize, ysize, Re, RT=RT, uLB=uLB, semantics=semantics, dtype=dtype, turb=turb, device=device, **extra)
     relax = solver.relax
     say("Re chosen  is ", Re)
     say("RT chosen is ", RT)
@@ -209,10 +210,11 @@ def main(argv=None):
     ap.add_argument("--OutputFolder", default="./output")
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
     ap.add_argument("--semantics", choices=["mrt_gpu", "mrt_py"], default="mrt_gpu")
+    ap.add_argument("--arith", choices=["strict", "fast"], default="strict")
     a = ap.parse_args(argv)
     r = run_cavity(maxIt=a.maxIt, Re=a.Re, RT=a.RT, turb=a.turb, xsize=a.xsize, ysize=a.ysize, uLB=a.uLB,
                    Pinterval=a.Pinterval, SavePlot=not a.no_plot, SaveVTK=a.vtk, project=a.project,
-                   OutputFolder=a.OutputFolder, dtype=np.dtype(a.dtype), semantics=a.semantics)
+                   OutputFolder=a.OutputFolder, dtype=np.dtype(a.dtype), semantics=a.semantics, arith=a.arith)
     print("MLUPS : ", r.mlups)
     return 0
 
