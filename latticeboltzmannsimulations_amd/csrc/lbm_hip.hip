@@ -110,7 +110,6 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
 // grown rectangles overlap, both workgroups write the same bits.  Each pass has its own scratch lattice (a ping-pong pair would
 // let a fast workgroup overwrite cells a slow neighbour still reads); the last pass writes lat[b].  Same per-cell operations as
 // S launches of k_step_frame.
-constexpr int FR_L = 64;
 template <typename R>
 struct FramePtrs {
     const R* src;    // state n
@@ -124,7 +123,7 @@ __device__ __forceinline__ R* pass_ptr(const FramePtrs<R>& fp, int j) {   // (se
 
 template <typename R, int COLL, int SEM, bool TURB, int NT>
 __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long boff, const Geo& geo, const Relax<R>& w, int F, int S,
-                                             int nsegx, int nsegy, int lo, int hi, int b) {
+                                             int nsegx, int nsegy, int lo, int hi, int b, int FR_L) {
     int x0, x1, y0, y1;   // owned rectangle [x0, x1) x [y0, y1)
     if (b < 2 * nsegx) {
         const int seg = b % nsegx;
@@ -150,10 +149,10 @@ __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long b
 
 template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, Relax<R> w, Batch<R> bt, int F, int S, int nsegx, int nsegy,
-                                                     int lo, int hi) {
+                                                     int lo, int hi, int seg) {
     long long boff = 0;
     if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
-    frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x);
+    frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg);
 }
 
 // S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS.  The
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, R
 template <typename R, int COLL, int SEM, int S, bool WIDE, bool TURB>
 __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                     Batch<R> bt, int F, int xe, int ye, int ntx, int ntiles, FramePtrs<R> fp, int nframe,
-                                                    int nsegx, int nsegy) {
+                                                    int nsegx, int nsegy, int seg) {
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
     constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
     __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
         // communication stream: nframe = 0).  The frame workgroups run S dependent passes and take the longest: they go first.
         long long boff = 0;
         if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
-        frame_passes<R, COLL, SEM, TURB, 512>(fp, boff, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x);
+        frame_passes<R, COLL, SEM, TURB, 512>(fp, boff, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg);
         return;
     }
     LBM_BATCH_SELECT(blockIdx.y)
@@ -312,6 +311,7 @@ struct lbm_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
+    int frame_seg = 64;         // cells of the frame per workgroup of the fused frame passes (LBM_FRAME_SEG)
  bool frame_fused = true;    // all frame passes of a multi-step in one launch (LBM_FRAME_FUSED=0: one launch per pass)
     int deep_rows = 0;          // ... and it was a deep one: this many complete rows per side (for the next multi-step)
     bool deep_halo = false;     // multi-steps between slabs exchange once per launch (MRT_GPU semantics; LBM_DEEP_HALO=0 disables)
@@ -492,9 +492,9 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
         FramePtrs<R> fp;
         fp.src = (const R*)c->lat[from];
         for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
-        const int F = c->tb_f, nsegx = (c->geo.nx + FR_L - 1) / FR_L, nsegy = (c->geo.ny - 2 * F + FR_L - 1) / FR_L;
+        const int F = c->tb_f, L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
         hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
-                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 : 0, hi ? 1 : 0);
+                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 : 0, hi ? 1 : 0, L);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -516,11 +516,11 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
                 FramePtrs<R> fp;
                 fp.src = (const R*)c->lat[from];
                 for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
-                const int nsegx = (c->geo.nx + FR_L - 1) / FR_L, nsegy = (c->geo.ny - 2 * F + FR_L - 1) / FR_L;
+                const int L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
                 const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
                 hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, VT::SEM, S, WIDE, VT::TURB>), dim3(nframe + ntx * nty, c->batch), dim3(512), 0, s,
                                    (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty,
-                                   fp, nframe, nsegx, nsegy);
+                                   fp, nframe, nsegx, nsegy, L);
             };
             if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
                 if (steps == 4) {
@@ -935,9 +935,12 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC;
         const bool can_tb = p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
         if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
-        // measured crossover (profiles/r01_logs/perf4.log): below ~768^2 cells a step is launch-bound and the three launches of
-        // a double step do not pay
-        const bool big = (long long)p->nx * p->ny_local * c->batch >= 768LL * 768LL;
+        // measured crossover: with one launch per frame pass (batches, LBM_FRAME_FUSED=0) a multi-step pays from ~768^2 cells
+        // (profiles/r01_logs/perf4.log); with the frame inside the tile launch a unit is ONE launch and wins from the smallest
+        // lattices the in-place kernel takes (perf41.log, perf43.log: 160^2 4.1-4.5 us per step against 5.1 one step per launch)
+        const bool one_launch = c->batch == 1 && p->ny_local == p->ny && !(std::getenv("LBM_FRAME_FUSED") && std::atoi(std::getenv("LBM_FRAME_FUSED")) == 0);
+        const bool big = one_launch ? (p->nx >= 64 && p->ny_local >= 64)
+                                    : (long long)p->nx * p->ny_local * c->batch >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
         // Steps per launch: the in-place LDS tile kernel with S = 4 (fp32) or 3 (fp64), also with the Smagorinsky closure (its
         // history is cell-local and stays in registers).  LBM_TB_STEPS=2..5 overrides (A/B, tests; 2 = the two-phase kernel).
@@ -965,6 +968,13 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // 4096^2 fp32 278 -> 294 GLUPS, 1024^2 fp64 67 -> 91, 1024^2 fp32 96 -> 135; a batch of 64 x 384^2 loses 5 % (its many
         // short frame workgroups do better as separate small launches), so batches keep one launch per pass
         c->frame_fused = !(ff && std::atoi(ff) == 0) && c->batch == 1;
+        // cells of the frame per workgroup (perf43.log): short segments finish a pass in one sweep of the workgroup and suit
+        // lattices whose launch is over when the frame chain is (160^2: 4.1 us per step with 16, 6.3 with 64); long ones compute
+        // less overlap and suit large lattices (2048^2: 244 GLUPS with 64, 215 with 16)
+        const long long cells1 = (long long)p->nx * p->ny_local;
+        c->frame_seg = cells1 <= 512LL * 512 ? 16 : (cells1 <= 1024LL * 1024 ? 32 : 64);
+        const char* fs = std::getenv("LBM_FRAME_SEG");
+        if (fs && std::atoi(fs) >= 8) c->frame_seg = std::atoi(fs);
         const char* dh = std::getenv("LBM_DEEP_HALO");
         c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(dh && std::atoi(dh) == 0);
         const char* nt = std::getenv("LBM_NT");
