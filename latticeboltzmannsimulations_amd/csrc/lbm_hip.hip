@@ -316,6 +316,8 @@ struct lbm_ctx {
     int deep_rows = 0;          // ... and it was a deep one: this many complete rows per side (for the next multi-step)
     bool deep_halo = false;     // multi-steps between slabs exchange once per launch (MRT_GPU semantics; LBM_DEEP_HALO=0 disables)
     bool loopback = false;      // diagnostic: 1-rank communicator, the slab exchanges halos with itself
+    int loop_sides = 3;         // ... through these sides (bit LBM_SIDE_LOW / LBM_SIDE_HIGH; LBM_DEBUG_LOOPBACK_SIDES: tests of the
+                                // one-neighbour code paths of the first / last rank; the other side then reads its never-written ghost rows)
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
@@ -594,6 +596,14 @@ int sync_all(lbm_ctx* c) {
     return LBM_OK;
 }
 
+// Does the slab have a neighbour through this side?  Between ranks: rank - 1 / rank + 1.  In loopback mode (one GPU, the slab
+// is its own neighbour) every side that is not a global wall wraps around.
+bool has_neighbour(const lbm_ctx* c, int side) {
+    if (c->loopback) return (c->loop_sides >> side) & 1;
+    if (c->nranks <= 1) return false;
+    return side == LBM_SIDE_LOW ? c->rank > 0 : c->rank < c->nranks - 1;
+}
+
 // RCCL exchange of the rows of lat[which] with both neighbours, on s_comm
 int enqueue_exchange(lbm_ctx* c, int which) {
     static const bool skip = std::getenv("LBM_DEBUG_SKIP_EXCHANGE") != nullptr;   // timing diagnostic only: wrong results
@@ -603,8 +613,8 @@ int enqueue_exchange(lbm_ctx* c, int which) {
     NCCL_TRY(c, rccl().GroupStart());
     for (int side = 0; side < 2; ++side) {
         int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
-        if (c->loopback) peer = 0;                 // the slab is its own neighbour on both sides
-        if (peer < 0 || peer >= c->nranks) continue;
+        if (c->loopback) peer = 0;                 // the slab is its own neighbour
+        if (!has_neighbour(c, side)) continue;
         // planes leaving / arriving through this side.  In loopback mode both sides talk to rank 0, and RCCL
         // pairs the i-th send to a peer with the i-th receive from it: what leaves through the OTHER side is
         // sent here, so that the HIGH row lands in the LOW ghost row and vice versa (periodic wrap).
@@ -646,7 +656,7 @@ int enqueue_deep_exchange(lbm_ctx* c, int which, int S) {
     for (int side = 0; side < 2; ++side) {
         int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
         if (c->loopback) peer = 0;
-        if (peer < 0 || peer >= c->nranks) continue;
+        if (!has_neighbour(c, side)) continue;
         const int sside = c->loopback ? (side ^ 1) : side;   // see enqueue_exchange
         const int send_r0 = sside == LBM_SIDE_LOW ? 0 : ny - S;
         const int recv_r0 = side == LBM_SIDE_LOW ? -S : ny;
@@ -732,7 +742,7 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, int S_next) {
         rc = deep ? enqueue_deep_exchange(c, a, S) : enqueue_exchange(c, a);
         if (rc) return rc;
     }
-    const bool has_lo = multi && (c->loopback || c->rank > 0), has_hi = multi && (c->loopback || c->rank < c->nranks - 1);
+    const bool has_lo = has_neighbour(c, LBM_SIDE_LOW), has_hi = has_neighbour(c, LBM_SIDE_HIGH);
     if (c->frame_fused && S >= 3 && (!multi || deep)) {
         rc = launch_frame_multi(c, a, b, S, c->s_comm, deep && has_lo, deep && has_hi);
         if (rc) return rc;
@@ -1230,6 +1240,9 @@ int lbm_comm_loopback(lbm_ctx* c) {
     if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
     if (c->geo.y0 == 0 || c->geo.y0 + c->geo.ny == c->geo.NY)
         return fail(c, LBM_ERR_INVALID, "lbm_comm_loopback needs a slab that touches neither the lid nor the bottom wall");
+    const char* ls = std::getenv("LBM_DEBUG_LOOPBACK_SIDES");
+    c->loop_sides = ls ? (std::atoi(ls) & 3) : 3;
+    if (c->loop_sides == 0) return fail(c, LBM_ERR_INVALID, "LBM_DEBUG_LOOPBACK_SIDES must be 1, 2 or 3");
     if (!rccl().ok) return fail(c, LBM_ERR_COMM, rccl().err);
     HIP_TRY(c, hipSetDevice(c->p.device));
     ncclUniqueId id;
