@@ -32,3 +32,13 @@ def test_wrong_world_size_is_refused():
     env = dict(os.environ, WORLD_SIZE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
     assert p.returncode != 0 and "torch.distributed.run" in (p.stderr + p.stdout)
+
+
+def test_traffic_table_has_the_default_bench_entry():
+    """bench.py fills roofline.traffic from profiles/traffic.json (PMC-measured HBM bytes per step of the same command)."""
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key in ("c3:1:auto:fast", "c3:1:auto:strict", "c3:1:vec:strict"):
+        assert t[key]["hbm_bytes_per_step"] > 0, key
+    # several steps per launch move less than the algorithmic 18 words per update; one step per launch moves about that
+    assert t["c3:1:auto:fast"]["hbm_bytes_per_step"] < 0.3 * t["c3:1:auto:fast"]["algorithmic_bytes_per_step"]
+    assert 0.95 < t["c3:1:vec:strict"]["hbm_bytes_per_step"] / (4096 * 4096 * 72) < 1.1
