@@ -311,66 +311,81 @@ struct Geo {
     __host__ __device__ __forceinline__ long long at(int x, int y) const { return (long long)(y + GHY) * row + GH + x; }
 };
 
+// The same (k, x, y) addressing for a small window of the lattice held in LDS (the fused frame passes keep the output of the
+// intermediate passes there): window origin (x0, y0), `pitch` elements per row, `plane` per direction.  gather / update_cell
+// take one addressing object for the source and one for the destination: Geo (a lattice in memory) or Window.
+struct Window {
+    int plane, pitch, x0, y0;
+    __device__ __forceinline__ int at(int x, int y) const { return (y - y0) * pitch + (x - x0); }
+};
+
 // Where a perimeter cell parks the density of its last macroscopic state: slot 0 of the
 // adjacent ghost cell (slot 0 of a ghost cell is never pulled).
-__device__ __forceinline__ long long wall_rho_at(const Geo& g, int x, int y, int gy) {
-    if (gy == 0) return g.at(x, y - 1);
-    if (gy == g.NY - 1) return g.at(x, y + 1);
-    if (x == 0) return g.at(-1, y);
-    return g.at(g.nx, y);
+template <typename A>
+__device__ __forceinline__ auto wall_rho_at(const A& a, const Geo& g, int x, int y, int gy) -> decltype(a.at(x, y)) {
+    if (gy == 0) return a.at(x, y - 1);
+    if (gy == g.NY - 1) return a.at(x, y + 1);
+    if (x == 0) return a.at(-1, y);
+    return a.at(g.nx, y);
 }
 
 // Gather the post-stream, post-wall-rule populations of cell (x, y) from a lattice that
 // holds post-collision values (+ kept slots + parked wall densities); raw != 0: the lattice
 // holds plain populations (state just set by the host), nothing to stream.
-template <typename R, int SEM>
-__device__ __forceinline__ void gather(const R* __restrict__ src, const Geo& geo, int raw, R uLB, int x, int y, R (&g)[Q]) {
+template <typename R, int SEM, typename AS>
+__device__ __forceinline__ void gather_a(const R* __restrict__ src, const AS& as, const Geo& geo, int raw, R uLB, int x, int y, R (&g)[Q]) {
     const int gy = geo.y0 + y;
     if (raw) {
 #pragma unroll
-        for (int k = 0; k < Q; ++k) g[k] = src[k * geo.plane + geo.at(x, y)];
+        for (int k = 0; k < Q; ++k) g[k] = src[k * as.plane + as.at(x, y)];
         return;
     }
 #pragma unroll
-    for (int k = 0; k < Q; ++k) g[k] = src[k * geo.plane + geo.at(x - cxk(k), y + cyk(k))];
+    for (int k = 0; k < Q; ++k) g[k] = src[k * as.plane + as.at(x - cxk(k), y + cyk(k))];
     if (x == 0 || x == geo.nx - 1 || gy == 0 || gy == geo.NY - 1) {
-        const R rho_w = src[wall_rho_at(geo, x, y, gy)];
+        const R rho_w = src[wall_rho_at(as, geo, x, y, gy)];
         R fe[Q];
         equ<R>(rho_w, gy == 0 ? uLB : (R)0, (R)0, fe);
         wall_rules<R, SEM>(g, fe, x, gy, geo.nx, geo.NY);
     }
 }
+template <typename R, int SEM>
+__device__ __forceinline__ void gather(const R* __restrict__ src, const Geo& geo, int raw, R uLB, int x, int y, R (&g)[Q]) {
+    gather_a<R, SEM, Geo>(src, geo, geo, raw, uLB, x, y, g);
+}
 
 // One fused update of cell (x, y): gather -> (kept slots) -> moments -> collide -> store.
-template <typename R, int COLL, int SEM, bool TURB = false>
-__device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
-                                            const Relax<R>& w0, int raw, int x, int y) {
+// as / ad: addressing of the source / destination (Geo = lattice in memory, Window = LDS window of the fused frame passes).
+template <typename R, int COLL, int SEM, bool TURB, typename AS, typename AD>
+__device__ __forceinline__ void update_cell_a(const R* __restrict__ src, const AS& as, R* __restrict__ dst, const AD& ad, const Geo& geo,
+                                              const Relax<R>& w0, int raw, int x, int y) {
     const int X = geo.nx, Y = geo.NY, gy = geo.y0 + y;
     R g[Q];
-    gather<R, SEM>(src, geo, raw, w0.uLB, x, y, g);
+    gather_a<R, SEM, AS>(src, as, geo, raw, w0.uLB, x, y, g);
     // kept slots: a slot outside its streaming window keeps its value; park it where the
     // next pull of this cell will look for it.
     const bool near_edge = (x <= 0) || (x >= X - 2) || (gy <= 0) || (gy >= Y - 2);
     if (near_edge) {
 #pragma unroll
         for (int k = 1; k < Q; ++k)
-            if (!in_window<SEM>(k, x, gy, X, Y)) dst[k * geo.plane + geo.at(x - cxk(k), y + cyk(k))] = g[k];
+            if (!in_window<SEM>(k, x, gy, X, Y)) dst[k * ad.plane + ad.at(x - cxk(k), y + cyk(k))] = g[k];
     }
     R rho, ux, uy, fe[Q], out[Q];
-    const long long me = geo.at(x, y);
+    const auto me = ad.at(x, y);
+    const auto me_s = as.at(x, y);
     const Relax<R>& w = w0;
     R w_nu = w0.w_nu;
-    if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, src[K_QEQ * geo.plane + me], src[K_RHO * geo.plane + me], w0.w_nu);
+    if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, src[K_QEQ * as.plane + me_s], src[K_RHO * as.plane + me_s], w0.w_nu);
     macros<R, coll_is_fast(COLL)>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
     equ<R>(rho, ux, uy, fe);
     collide<R, COLL>(g, rho, fe, w, w_nu, out);
     if (TURB) {
-        dst[K_QEQ * geo.plane + me] = diag_flux<R>(fe);
-        dst[K_RHO * geo.plane + me] = rho;
+        dst[K_QEQ * ad.plane + me] = diag_flux<R>(fe);
+        dst[K_RHO * ad.plane + me] = rho;
     }
     if (!near_edge) {
 #pragma unroll
-        for (int k = 0; k < Q; ++k) dst[k * geo.plane + me] = out[k];
+        for (int k = 0; k < Q; ++k) dst[k * ad.plane + me] = out[k];
     } else {
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
@@ -378,10 +393,16 @@ __device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __rest
             // cell's kept slot, written by the receiving cell itself)
             const int dx = x + cxk(k), dgy = gy - cyk(k);
             const bool inside = dx >= 0 && dx < X && dgy >= 0 && dgy < Y;
-            if (!inside || in_window<SEM>(k, dx, dgy, X, Y)) dst[k * geo.plane + me] = out[k];
+            if (!inside || in_window<SEM>(k, dx, dgy, X, Y)) dst[k * ad.plane + me] = out[k];
         }
-        if (x == 0 || x == X - 1 || gy == 0 || gy == Y - 1) dst[wall_rho_at(geo, x, y, gy)] = rho;
+        if (x == 0 || x == X - 1 || gy == 0 || gy == Y - 1) dst[wall_rho_at(ad, geo, x, y, gy)] = rho;
     }
+}
+
+template <typename R, int COLL, int SEM, bool TURB = false>
+__device__ __forceinline__ void update_cell(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
+                                            const Relax<R>& w0, int raw, int x, int y) {
+    update_cell_a<R, COLL, SEM, TURB, Geo, Geo>(src, geo, dst, geo, geo, w0, raw, x, y);
 }
 
 // ------------------------------------------------------------------------------------------

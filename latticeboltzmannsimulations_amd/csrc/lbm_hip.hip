@@ -121,9 +121,12 @@ __device__ __forceinline__ R* pass_ptr(const FramePtrs<R>& fp, int j) {   // (se
     return j == 0 ? fp.pass[0] : j == 1 ? fp.pass[1] : j == 2 ? fp.pass[2] : j == 3 ? fp.pass[3] : fp.pass[4];
 }
 
+// LDS bytes a workgroup of the fused frame passes may use (= the tile kernel's buffer)
+constexpr int FRAME_LDS_BYTES = 48 * 1024;
+
 template <typename R, int COLL, int SEM, bool TURB, int NT>
 __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long boff, const Geo& geo, const Relax<R>& w, int F, int S,
-                                             int nsegx, int nsegy, int lo, int hi, int b, int FR_L) {
+                                             int nsegx, int nsegy, int lo, int hi, int b, int FR_L, R* lds) {
     int x0, x1, y0, y1;   // owned rectangle [x0, x1) x [y0, y1)
     if (b < 2 * nsegx) {
         const int seg = b % nsegx;
@@ -134,6 +137,44 @@ __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long b
         const int seg = b % nsegy;
         y0 = F + seg * FR_L; y1 = min(geo.ny - F, y0 + FR_L);
         x0 = b < nsegy ? 0 : geo.nx - F; x1 = x0 + F;
+    }
+    if (lds) {
+        // The output of the intermediate passes stays in LDS: a window = the rectangle of pass 1 plus a ring of one cell (ghost
+        // positions where wall cells park kept slots and densities), two buffers in turn.  Pass 1 reads the lattice, the last
+        // pass writes the lattice; every window entry a pass reads was written by the pass before (or is overwritten by a wall
+        // rule before use); the window is zeroed first so that such dead reads see numbers.
+        constexpr int NP = TURB ? Q + 2 : Q;
+        const int m1 = S - 1;
+        const int xa1 = max(0, x0 - m1), xb1 = min(geo.nx, x1 + m1);
+        const int ya1 = max(lo ? -m1 : 0, y0 - m1), yb1 = min(geo.ny + (hi ? m1 : 0), y1 + m1);
+        Window win;
+        win.x0 = xa1 - 1; win.y0 = ya1 - 1; win.pitch = xb1 - xa1 + 2; win.plane = win.pitch * (yb1 - ya1 + 2);
+        R* const buf0 = lds;
+        R* const buf1 = lds + NP * win.plane;
+        for (int t = threadIdx.x; t < 2 * NP * win.plane; t += NT) lds[t] = (R)0;
+        __syncthreads();
+        for (int i = 1; i <= S; ++i) {
+            const int m = S - i;
+            const int xa = max(0, x0 - m), xb = min(geo.nx, x1 + m);
+            const int ya = max(lo ? -m : 0, y0 - m), yb = min(geo.ny + (hi ? m : 0), y1 + m);
+            const int wx = xb - xa, n = wx * (yb - ya);
+            R* const wr = (i & 1) ? buf0 : buf1;
+            const R* const rd = (i & 1) ? buf1 : buf0;
+            if (i == 1) {
+                const R* src = fp.src + boff;
+                for (int t = threadIdx.x; t < n; t += NT)
+                    update_cell_a<R, COLL, SEM, TURB, Geo, Window>(src, geo, wr, win, geo, w, 0, xa + t % wx, ya + t / wx);
+            } else if (i < S) {
+                for (int t = threadIdx.x; t < n; t += NT)
+                    update_cell_a<R, COLL, SEM, TURB, Window, Window>(rd, win, wr, win, geo, w, 0, xa + t % wx, ya + t / wx);
+            } else {
+                R* dst = pass_ptr(fp, S - 1) + boff;
+                for (int t = threadIdx.x; t < n; t += NT)
+                    update_cell_a<R, COLL, SEM, TURB, Window, Geo>(rd, win, dst, geo, geo, w, 0, xa + t % wx, ya + t / wx);
+            }
+            __syncthreads();
+        }
+        return;
     }
     for (int i = 1; i <= S; ++i) {
         const int m = S - i;
@@ -149,10 +190,11 @@ __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long b
 
 template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, Relax<R> w, Batch<R> bt, int F, int S, int nsegx, int nsegy,
-                                                     int lo, int hi, int seg) {
+                                                     int lo, int hi, int seg, int use_lds) {
+    __shared__ __align__(16) R lds[FRAME_LDS_BYTES / sizeof(R)];
     long long boff = 0;
     if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
-    frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg);
+    frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg, use_lds ? lds : nullptr);
 }
 
 // S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS.  The
@@ -163,7 +205,7 @@ __global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, R
 template <typename R, int COLL, int SEM, int S, bool WIDE, bool TURB>
 __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
                                                     Batch<R> bt, int F, int xe, int ye, int ntx, int ntiles, FramePtrs<R> fp, int nframe,
-                                                    int nsegx, int nsegy, int seg) {
+                                                    int nsegx, int nsegy, int seg, int use_lds) {
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
     constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
     __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
@@ -173,7 +215,8 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
         // communication stream: nframe = 0).  The frame workgroups run S dependent passes and take the longest: they go first.
         long long boff = 0;
         if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
-        frame_passes<R, COLL, SEM, TURB, 512>(fp, boff, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg);
+        static_assert(sizeof(lds_raw) >= FRAME_LDS_BYTES, "frame window buffer");
+        frame_passes<R, COLL, SEM, TURB, 512>(fp, boff, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg, use_lds ? lds_raw : nullptr);
         return;
     }
     LBM_BATCH_SELECT(blockIdx.y)
@@ -311,6 +354,7 @@ struct lbm_ctx {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
+    bool frame_lds = true;      // ... keeping the intermediate passes in LDS when their windows fit (LBM_FRAME_LDS=0: scratch lattices)
     int frame_seg = 64;         // cells of the frame per workgroup of the fused frame passes (LBM_FRAME_SEG)
  bool frame_fused = true;    // all frame passes of a multi-step in one launch (LBM_FRAME_FUSED=0: one launch per pass)
     int deep_rows = 0;          // ... and it was a deep one: this many complete rows per side (for the next multi-step)
@@ -487,6 +531,15 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0
 
 // All S frame passes lat[from] -> lat[to] in one launch (k_frame_multi); lo / hi: the slab has a neighbour below row 0 / above
 // row ny - 1 whose rows lie in the ghost rows (deep halo).
+// Do the LDS windows of the fused frame passes fit (two buffers of the largest pass-1 rectangle plus its ring)?
+bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows) {
+    if (!c->frame_lds) return false;
+    const int F = c->tb_f, L = c->frame_seg, m = S - 1, np = c->p.turb ? Q + 2 : Q;
+    const long long row_strip = (long long)(L + 2 * m + 2) * (F + m + (deep_rows ? m : 0) + 2);
+    const long long col_strip = (long long)(F + m + 2) * (L + 2 * m + 2);
+    return 2 * np * std::max(row_strip, col_strip) * c->es <= FRAME_LDS_BYTES;
+}
+
 int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool lo, bool hi) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
@@ -496,7 +549,7 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
         for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
         const int F = c->tb_f, L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
         hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
-                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 : 0, hi ? 1 : 0, L);
+                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 : 0, hi ? 1 : 0, L, frame_lds_fits(c, S, lo || hi) ? 1 : 0);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -522,7 +575,7 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
                 const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
                 hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, VT::SEM, S, WIDE, VT::TURB>), dim3(nframe + ntx * nty, c->batch), dim3(512), 0, s,
                                    (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty,
-                                   fp, nframe, nsegx, nsegy, L);
+                                   fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false) ? 1 : 0);
             };
             if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
                 if (steps == 4) {
@@ -985,6 +1038,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->frame_seg = cells1 <= 512LL * 512 ? 16 : (cells1 <= 1024LL * 1024 ? 32 : 64);
         const char* fs = std::getenv("LBM_FRAME_SEG");
         if (fs && std::atoi(fs) >= 8) c->frame_seg = std::atoi(fs);
+        const char* fl = std::getenv("LBM_FRAME_LDS");
+        c->frame_lds = !(fl && std::atoi(fl) == 0);
         const char* dh = std::getenv("LBM_DEEP_HALO");
         c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(dh && std::atoi(dh) == 0);
         const char* nt = std::getenv("LBM_NT");
