@@ -635,15 +635,16 @@ __device__ __forceinline__ void update_tile2(const R* __restrict__ src, R* __res
 constexpr int TB_LDS_PLANES = 6;
 __host__ __device__ constexpr int lds_slot(int k) { return k == 2 ? 0 : k == 4 ? 1 : k - 3; }   // 5,6,7,8 -> 2,3,4,5
 
-template <typename R, int COLL, int V, int TX, int TY, int S, bool TURB>
+template <typename R, int COLL, int V, int TX, int TY, int S, bool TURB, int RV = 1>
 __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo,
                                                     const Relax<R>& w, R* __restrict__ lds, int tx0, int ty0, int xe, int ye) {
+    // RV: vector cells of rim on each side in x (fp64 vectors hold two cells: more than three steps need two of them)
     typedef typename VecT<R, V>::type T;
-    constexpr int PW = TX + 2 * V, PH = TY + 2 * (S - 1), PVC = PW / V;
-    static_assert(S - 1 <= V, "the x rim is only V cells wide");
+    constexpr int PW = TX + 2 * RV * V, PH = TY + 2 * (S - 1), PVC = PW / V;
+    static_assert(S - 1 <= RV * V, "the x rim is RV * V cells wide");
     static_assert(64 % PVC == 0, "a row of vector cells must not straddle two waves");
     const int r = threadIdx.x / PVC, vc = threadIdx.x % PVC;
-    const int x0 = tx0 - V + vc * V, y = ty0 - (S - 1) + r;
+    const int x0 = tx0 - RV * V + vc * V, y = ty0 - (S - 1) + r;
     T in[Q], outv[Q], hq, hr;
     const bool inside = x0 < geo.nx && y < geo.ny;
     if (inside) {
@@ -695,9 +696,9 @@ __device__ __forceinline__ void update_tile_inplace(const R* __restrict__ src, R
         }
         if (s < S) __syncthreads();   // everyone has read before anyone overwrites in place
         // (the rim columns are needed by the next step but not after the last one)
-        if (act && (s < S || (vc >= 1 && vc < PVC - 1))) collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);
+        if (act && (s < S || (vc >= RV && vc < PVC - RV))) collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);
     }
-    if (r >= S - 1 && r < PH - (S - 1) && vc >= 1 && vc < PVC - 1 && x0 < xe && y < ye) {
+    if (r >= S - 1 && r < PH - (S - 1) && vc >= RV && vc < PVC - RV && x0 < xe && y < ye) {
         const long long me = geo.at(x0, y);
 #pragma unroll
         for (int k = 0; k < Q; ++k) vstore<R, V, false>(dst + k * geo.plane + me, outv[k]);

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
                                                     Batch<R> bt, int F, int xe, int ye, int ntx, int ntiles, FramePtrs<R> fp, int nframe,
                                                     int nsegx, int nsegy, int seg, int use_lds) {
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
-    constexpr int TX = (PVC - 2) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * V;
+    constexpr int RV = (S - 1 + V - 1) / V;        // rim vectors per side: 1, or 2 for fp64 beyond three steps
+    constexpr int TX = (PVC - 2 * RV) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * RV * V;
     __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
     if ((int)blockIdx.x < nframe) {                                         // read one element past their row
         // A lone lattice: the first nframe workgroups of the launch do the S frame passes (frame_passes), the rest the tiles --
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
     int b = blockIdx.x - nframe;
     const int per = ntiles >> 3;
     if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
-    update_tile_inplace<R, COLL, V, TX, TY, S, TURB>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
+    update_tile_inplace<R, COLL, V, TX, TY, S, TURB, RV>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
 }
 
 // One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
@@ -566,7 +567,7 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
             auto go = [&](auto steps, auto wide) {
                 constexpr int S = decltype(steps)::value;
                 constexpr bool WIDE = decltype(wide)::value;
-                constexpr int PVC = WIDE ? 32 : 16, TX = (PVC - 2) * V, TY = 512 / PVC - 2 * (S - 1);
+                constexpr int PVC = WIDE ? 32 : 16, RV = (S - 1 + V - 1) / V, TX = (PVC - 2 * RV) * V, TY = 512 / PVC - 2 * (S - 1);
                 const int ntx = (xe - F + TX - 1) / TX, nty = (ye - F + TY - 1) / TY;
                 FramePtrs<R> fp;
                 fp.src = (const R*)c->lat[from];
@@ -577,17 +578,9 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
                                    (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty,
                                    fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false) ? 1 : 0);
             };
-            if constexpr (V >= 4) {   // the x rim is V cells wide: S steps need V >= S - 1 (fp32 only beyond three)
-                if (steps == 4) {
-                    if (c->tb3_wide) go(std::integral_constant<int, 4>{}, std::true_type{});
-                    else go(std::integral_constant<int, 4>{}, std::false_type{});
-                    return;
-                }
-                if (steps == 5) {
-                    if (c->tb3_wide) go(std::integral_constant<int, 5>{}, std::true_type{});
-                    else go(std::integral_constant<int, 5>{}, std::false_type{});
-                    return;
-                }
+            {   // (fp64: the x rim of S >= 4 is two vectors wide)
+                if (steps == 4) { go(std::integral_constant<int, 4>{}, std::false_type{}); return; }   // (the wide region exists for
+                if (steps == 5) { go(std::integral_constant<int, 5>{}, std::false_type{}); return; }   // three steps only)
             }
             if (c->tb3_wide) go(std::integral_constant<int, 3>{}, std::true_type{});
             else go(std::integral_constant<int, 3>{}, std::false_type{});
@@ -1018,8 +1011,11 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // 217; MRT + closure 150 / 187 / 202; TRT 185 / 210 / 210, with the closure 152 / 163 / 156
         const bool fast = p->arith == LBM_ARITH_FAST;
         const int want32 = fast ? (p->collision == LBM_TRT ? 4 : 5) : (trt_turb ? 3 : 4);
-        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 ? want32 : 3);
-        const bool deep_ok = p->dtype == LBM_F32 && p->nx >= 64 && p->ny_local >= 64;
+        // fp64 (perf46.log; an x rim of two vectors from four steps on): the factored MRT operator S = 3 / 4 / 5 = 98 / 123 / 142 GLUPS
+        // at 4096^2 (8192 x 1024: 91 / 109 / 129); the strict operator is arithmetic-bound (103 / 105 / 103)
+        const int want64 = fast && p->collision == LBM_MRT ? 5 : 3;
+        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 ? want32 : want64);
+        const bool deep_ok = p->nx >= 64 && p->ny_local >= 64;
         c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
         c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
         // tile shape of the three-step kernel, A/B in one run (profiles/r01_logs/perf14.log): 14 vectors x 28 rows beats

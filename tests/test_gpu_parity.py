@@ -113,11 +113,23 @@ def test_two_steps_per_launch_is_bit_identical_to_oracle(sem, coll, dtype):
             same(s, o, "tb after set_state")
 
 
+@pytest.mark.parametrize("sem,coll", [("mrt_gpu", "MRT"), ("mrt_py", "SRT")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_multi_step_on_thin_and_wide_lattices(sem, coll, dtype):
+    """Shapes at the limits of the multi-step path: 64 cells in one direction (the frame of width 8 leaves 48), very wide and
+    very tall; frame segments of every default length (16 / 32) and the LDS windows of the fused frame passes."""
+    for nx, ny, steps in ((1028, 64, 23), (64, 516, 23), (2052, 68, 12), (640, 640, 11)):
+        o = CavityOracleC(nx, ny, 400.0, semantics=sem, collision=coll, dtype=dtype).step(steps)
+        with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=dtype) as s:      # kernel = auto
+            s.step(steps)
+            same(s, o, f"{nx}x{ny} {sem} {coll}")
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_two_and_three_steps_per_launch_agree(monkeypatch, dtype):
     """The interior advances three steps per launch by default (two with LBM_TB_STEPS=2): same bits either way."""
     o = CavityOracleC(132, 99, 400.0, semantics="mrt_gpu", collision="MRT", dtype=dtype).step(47)
-    for steps in ("2", "3", "4", "5"):   # four, five: fp32 only (fp64 silently stays at three)
+    for steps in ("2", "3", "4", "5"):   # (fp64: the x rim of the tiles is two vectors wide from four steps on)
         monkeypatch.setenv("LBM_TB_STEPS", steps)
         with CavitySolver(132, 99, 400.0, RT="MRT", dtype=dtype, kernel="tb") as s:
             s.step(47)
