@@ -69,7 +69,8 @@ typedef struct lbm_params {
                             the CPU restatement in oracle/.  LBM_ARITH_FAST: the MRT operator in an algebraically identical
                             factored form with fused multiply-adds (about half the arithmetic); in fp32 also u = j * rcp(rho)
                             and the Smagorinsky closure's divisions / square root by the 1-ulp hardware instructions.
-                            Results agree with the strict form to rounding, not bit for bit. */
+                            Results agree with the strict form to rounding, not bit for bit.  MRT_GPU semantics only
+                            (with LBM_SEM_MRT_PY the strict form is used). */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */
     double omega;        /* = omegap = omega_nu, MRT_GPU.py:65 */
     double omegam;       /* TRT, MRT_GPU.py:80 */

@@ -367,7 +367,6 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
     int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel)
-    bool tb3_wide = false;      // tile shape of the three/four-step kernel: region 32 vectors x 16 rows instead of 16 x 32
     int tb_f = TB_F;            // frame width
     int batch = 1;              // independent lattices per buffer (lbm_params.batch)
     long long bstride = 0;      // elements from one lattice of the batch to the next
@@ -466,7 +465,8 @@ void dispatch(const lbm_params& p, F&& f) {
     auto by_sem = [&](auto real, auto coll) {
         using R = decltype(real);
         constexpr int C = decltype(coll)::value;
-        if (p.semantics == LBM_SEM_MRT_PY) f(Variant<R, C, SEM_PY, false>{});
+        constexpr int CS = C == C_MRT_FAST ? C_MRT : (C == C_SRT_FAST ? C_SRT : (C == C_TRT_FAST ? C_TRT : C));
+        if (p.semantics == LBM_SEM_MRT_PY) f(Variant<R, CS, SEM_PY, false>{});   // (arith = fast: MRT_GPU semantics only)
         else if (p.turb) f(Variant<R, C, SEM_GPU, true>{});
         else f(Variant<R, C, SEM_GPU, false>{});
     };
@@ -579,11 +579,10 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
                                    fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false) ? 1 : 0);
             };
             {   // (fp64: the x rim of S >= 4 is two vectors wide)
-                if (steps == 4) { go(std::integral_constant<int, 4>{}, std::false_type{}); return; }   // (the wide region exists for
-                if (steps == 5) { go(std::integral_constant<int, 5>{}, std::false_type{}); return; }   // three steps only)
+                if (steps == 4) { go(std::integral_constant<int, 4>{}, std::false_type{}); return; }
+                if (steps == 5) { go(std::integral_constant<int, 5>{}, std::false_type{}); return; }
             }
-            if (c->tb3_wide) go(std::integral_constant<int, 3>{}, std::true_type{});
-            else go(std::integral_constant<int, 3>{}, std::false_type{});
+            go(std::integral_constant<int, 3>{}, std::false_type{});
             return;
         }
         constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<VT::TURB>() * V, TY = tb_ty<VT::TURB>();
@@ -1019,9 +1018,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
         c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
         // tile shape of the three-step kernel, A/B in one run (profiles/r01_logs/perf14.log): 14 vectors x 28 rows beats
-        // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  LBM_TB3_WIDE=1 selects 30 x 12.
-        const char* shp = std::getenv("LBM_TB3_WIDE");
-        c->tb3_wide = shp && std::atoi(shp) != 0;
+        // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  (The wide variant is no longer compiled.)
         const char* ff = std::getenv("LBM_FRAME_FUSED");
         // measured (profiles/r01_logs/perf37.log, perf38.log): one launch per unit instead of S + 1 and no cross-stream dependency:
         // 4096^2 fp32 278 -> 294 GLUPS, 1024^2 fp64 67 -> 91, 1024^2 fp32 96 -> 135; a batch of 64 x 384^2 loses 5 % (its many
