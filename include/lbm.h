@@ -37,10 +37,10 @@ enum { LBM_F32 = 0, LBM_F64 = 1 };                      /* storage and arithmeti
 enum { LBM_SRT = 0, LBM_TRT = 1, LBM_MRT = 2 };         /* RT = 'SRT' | 'TRT' | 'MRT'  (MRT_GPU.py:48) */
 enum { LBM_SEM_MRT_PY = 0, LBM_SEM_MRT_GPU = 1 };       /* streaming windows + wall rules of MRT.py:404-453
                                                            or of MRT_GPU.py:412,674-692 */
-enum { LBM_KERNEL_AUTO = 0,      /* fastest applicable: TB, else VEC, else GENERIC */
+enum { LBM_KERNEL_AUTO = 0,      /* fastest applicable: TB (lattices from 64 x 64 cells), else VEC, else GENERIC */
        LBM_KERNEL_GENERIC = 1,   /* one step per launch, one thread per cell (all semantics) */
        LBM_KERNEL_VEC = 2,       /* one step per launch, 16 B per access (MRT_GPU semantics) */
-       LBM_KERNEL_TB = 3 };      /* two steps per launch on the interior through LDS + single steps on the frame */
+       LBM_KERNEL_TB = 3 };      /* several (3 .. 5) time steps per launch: tiles through LDS + the wall frame */
 enum { LBM_LAYOUT_AUTO = 0, LBM_LAYOUT_PLANES = 1, LBM_LAYOUT_ROWS = 2 }; /* device arrays: [k][y][x] or [y][k][x] */
 enum { LBM_ARITH_STRICT = 0, LBM_ARITH_FAST = 1 };
 enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour towards smaller / larger y */

@@ -365,7 +365,7 @@ struct lbm_ctx {
                                 // one-neighbour code paths of the first / last rank; the other side then reads its never-written ghost rows)
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
-    bool use_tb = false;        // two steps per launch on the interior (temporal blocking)
+    bool use_tb = false;        // several steps per launch (temporal blocking)
     int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel)
     int tb_f = TB_F;            // frame width
     int batch = 1;              // independent lattices per buffer (lbm_params.batch)
@@ -517,7 +517,7 @@ int launch_rows(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
     return LBM_OK;
 }
 
-// One single step on the frame of width W, lat[from] -> lat[to] (part of a double step; never a raw lattice).
+// One single step on the frame of width W, lat[from] -> lat[to] (one pass of a multi-step; never a raw lattice).
 int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0, int ehi = 0) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
@@ -721,7 +721,7 @@ int enqueue_deep_exchange(lbm_ctx* c, int which, int S) {
     return LBM_OK;
 }
 
-// Every step unit (one single step or one double step) follows one protocol on the two streams:
+// Every step unit (one single step or one multi-step) between slabs follows one protocol on the two streams:
 //   s_comm    (highest priority): waits ev_int (interior work of the previous unit), runs the wall / slab-edge work of
 //                                 this unit and the RCCL exchanges, records ev_edges;
 //   s_compute                   : waits ev_edges of the PREVIOUS unit, runs the bulk kernel, records ev_int.
@@ -750,7 +750,7 @@ int single_step(lbm_ctx* c, bool* comm_used) {
         *comm_used = true;
         return LBM_OK;
     }
-    if (c->use_tb) HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier double step
+    if (c->use_tb) HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier multi-step
     int rc = launch_rows(c, 0, 1, ny, c->s_compute);
     if (rc) return rc;
     if (c->use_tb) HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));

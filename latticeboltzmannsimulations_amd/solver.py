@@ -38,7 +38,7 @@ class CavitySolver:
     dtype        : float32 (what MRT_GPU.py stores, MRT_GPU.py:207) or float64 (what MRT.py computes in)
     rows         : (y0, ny_local) when this object holds only a slab
     kernel       : 'auto' | 'generic' (one thread per cell) | 'vec' (16 B per access, MRT_GPU.py semantics) |
-                   'tb' (two steps per launch on the interior through LDS; what 'auto' picks when it applies)
+                   'tb' (three to five steps per launch through LDS; what 'auto' picks when it applies)
     layout       : device arrays 'planes' [k][y][x], 'rows' [y][k][x], 'auto' (= rows)
     arith        : 'strict' (default; the reference's operation order, bit-identical to the CPU restatement the tests check against) or 'fast' (MRT operator
                    in factored form, about half the arithmetic, agrees to rounding)
