@@ -102,3 +102,15 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("oracle/", "").lower() or f == "__never__", (f, "mentions the oracle")
+
+
+def test_integration_md_binding_matches_the_struct():
+    """The ctypes stub shown in INTEGRATION.md must describe the same struct as include/lbm.h / _lib.lbm_params."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"c_int32\) for n in \((.*?)\)\] \+.*?c_double\) for n in \((.*?)\)\]", txt, re.S)
+    ints = re.findall(r'"(\w+)"', m.group(1))
+    dbls = re.findall(r'"(\w+)"', m.group(2))
+    assert ints + dbls == [f[0] for f in _lib.lbm_params._fields_]
+    hdr = open(os.path.join(ROOT, "include", "lbm.h")).read()
+    body = hdr[hdr.index("typedef struct lbm_params {"):hdr.index("} lbm_params;")]
+    assert re.findall(r"^\s+(?:int32_t|double)\s+(\w+);", body, re.M) == ints + dbls
