@@ -245,6 +245,9 @@ def main():
                        "halo": "rccl send/recv inside lbm_step, overlapped" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         # the bytes really moved (PMC, per step) over the same time: the physical HBM rate of the launch mix
+                         "traffic_GBps": None if traffic is None else round(traffic / (step_ms * 1e-3) / 1e9, 1),
+                         "traffic_frac_of_peak": None if traffic is None else round(traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "event_ms_per_step": round(step_ms, 5), "algorithmic_bytes_per_step": alg_bytes_step,
                          "note": "achieved = algorithmic bytes (18 words per cell update) / HIP-event time; with several time steps "
                                  "fused per launch through LDS the HBM bytes actually moved (traffic, per step) are below the "
