@@ -626,29 +626,36 @@ def test_fp32_tracks_fp64():
     assert np.abs(rf - rd).max() < 2e-5
 
 
-def test_full_size_properties_4096_fp32():
-    """BASELINE.json configs[2] size (4096^2, fp32, MRT): properties that need no CPU oracle run --
-    4 slabs == 1 slab bit for bit, one-step kernels == default (two-steps-per-launch) kernel, mass drift bounded."""
-    n, steps = 4096, 8
-    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as one:
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_full_size_properties_4096_fp32(arith):
+    """BASELINE.json configs[2] size (4096^2, fp32, MRT; both arithmetic forms -- `fast` is what bench.py times): properties
+    that need no CPU oracle run -- 4 slabs == 1 lattice bit for bit, one-step kernels == default (multi-step) kernel, mass
+    drift bounded; the fast form within 2e-5 of the strict one."""
+    n, steps = 4096, 13           # raw first step, two multi-step launches, one single step
+    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, arith=arith) as one:
         one.step(steps)
         u1, r1, f1 = one.get_fields(want_fin=True)
     assert np.isfinite(f1).all()
     mass0 = float(n) * n                                   # rho = 1 everywhere at t = 0
     assert abs(f1.sum(dtype=np.float64) - mass0) / mass0 < 1e-4
     for kern in ("generic", "vec"):
-        with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, kernel=kern) as g:
+        with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, kernel=kern, arith=arith) as g:
             g.step(steps)
             ug, rg, fg = g.get_fields(want_fin=True)
         assert np.array_equal(fg, f1) and np.array_equal(ug, u1) and np.array_equal(rg, r1), kern
         del ug, rg, fg
-    slabs = [CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, rows=r) for r in partition_rows(n, 4)]
+    slabs = [CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, rows=r, arith=arith) for r in partition_rows(n, 4)]
     LocalSlabs(slabs).step(steps)
     u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
     for s in slabs:
         s.get_fields(u=u, rho=rho, fin=fin)
         s.close()
     assert np.array_equal(fin, f1) and np.array_equal(u, u1) and np.array_equal(rho, r1)
+    if arith == "fast":
+        with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as ref:
+            ref.step(steps)
+            fs = ref.get_fields(want_fin=True)[2]
+        assert not np.array_equal(fs, f1) and np.abs(fs - f1).max() / np.abs(fs).max() < 2e-5
 
 
 def test_rccl_single_rank_communicator_is_transparent():
