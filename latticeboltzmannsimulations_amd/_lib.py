@@ -41,11 +41,33 @@ def sources():
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into liblbm_hip.so next to this file (in-tree)."""
+    """Compile csrc/*.hip for gfx950 into liblbm_hip.so next to this file (in-tree).  The translation units (host code + C ABI,
+    and the explicit instantiations of the multi-step tile kernel for float and for double) are compiled in parallel into
+    csrc/_obj/ and linked; LBM_SINGLE_TU=1 compiles lbm_hip.hip alone, instantiating everything there."""
     srcs = sources()
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
-    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH] + [s for s in srcs if s.endswith(".hip")] + LINK_FLAGS
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    if os.environ.get("LBM_SINGLE_TU"):
+        cmd = [HIPCC] + HIPCC_FLAGS + ["-DLBM_SINGLE_TU", "-o", LIB_PATH, os.path.join(_CSRC, "lbm_hip.hip")] + LINK_FLAGS
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(_CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    units = [s for s in srcs if s.endswith(".hip")]
+    objs = [os.path.join(objdir, os.path.basename(u)[:-4] + ".o") for u in units]
+
+    def compile_one(pair):
+        cmd = [HIPCC] + cflags + ["-c", pair[0], "-o", pair[1]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=len(units)) as pool:
+        list(pool.map(compile_one, zip(units, objs)))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + LINK_FLAGS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

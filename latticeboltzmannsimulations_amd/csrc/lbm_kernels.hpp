@@ -1,0 +1,321 @@
+// lbm_kernels.hpp -- the __global__ kernels of liblbm_hip.so (templates; see lbm_device.hpp for the per-cell operators).
+// Included by lbm_hip.hip (host code + C ABI) and by lbm_tiles_f32.hip / lbm_tiles_f64.hip, which hold the explicit
+// instantiations of the multi-step tile kernel so that the three translation units compile in parallel (lbm_tiles_inst.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lbm_device.hpp"
+
+using namespace lbm;
+
+constexpr int BLK = 256;
+
+// A batch of independent lattices advanced by one launch (lbm_params.batch): lattice z of the batch lives `stride` elements
+// further on in every device buffer and has its own relaxation rates w[z].  w == nullptr: a single lattice, rates by value.
+template <typename R>
+struct Batch {
+    long long stride;
+    const Relax<R>* w;
+};
+#define LBM_BATCH_SELECT(z)            \
+    if (bt.w) {                        \
+        src += (z) * bt.stride;        \
+        dst += (z) * bt.stride;        \
+        w = bt.w[(z)];                 \
+    }
+
+// Generic fused step: one thread per cell, rows y = row0 + blockIdx.y * row_stride.
+template <typename R, int COLL, int SEM, bool TURB>
+__global__ __launch_bounds__(BLK) void k_step_generic(const R* __restrict__ src, R* __restrict__ dst, Geo geo,
+                                                      Relax<R> w, Batch<R> bt, int raw, int row0, int row_stride) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = row0 + blockIdx.y * row_stride;
+    if (x >= geo.nx) return;
+    LBM_BATCH_SELECT(blockIdx.z)
+    update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, raw, x, y);
+}
+
+// Vector fused step (MRT_GPU.py semantics): 1-D grid of nrows * nxb blocks; a block owns
+// BLK * V consecutive cells of one row.  Blocks are dealt round-robin to the 8 XCDs, so block
+// b is remapped such that every XCD walks its own contiguous band of rows (measured +5 % on
+// the 18-stream access pattern; speed only, any placement is correct).
+#ifndef LBM_VEC_MIN_WAVES
+#define LBM_VEC_MIN_WAVES 1
+#endif
+template <typename R, int COLL, int V, bool NT, bool TURB>
+__global__ __launch_bounds__(BLK, LBM_VEC_MIN_WAVES) void k_step_vec(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+                                                  Batch<R> bt, int raw, int row0, int row_stride, int nxb, int nblocks) {
+    LBM_BATCH_SELECT(blockIdx.y)
+    int b = blockIdx.x;
+    const int per = nblocks >> 3;
+    if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
+    const int y = row0 + (b / nxb) * row_stride;
+    const int gy = geo.y0 + y;
+    if (gy == 0 || gy == geo.NY - 1) {
+        // lid / bottom-wall row: one cell per thread and pass (consecutive threads -> consecutive cells), so that a
+        // narrow lattice needs ONE pass instead of V dependent ones -- on small lattices this row is the critical path
+        const int xb0 = (b % nxb) * BLK * V;
+#pragma unroll 1
+        for (int j = 0; j < V; ++j) {
+            const int x = xb0 + j * BLK + threadIdx.x;
+            if (x < geo.nx) update_cell<R, COLL, SEM_GPU, TURB>(src, dst, geo, w, raw, x, y);
+        }
+        return;
+    }
+    const int x0 = ((b % nxb) * BLK + threadIdx.x) * V;
+    if (x0 >= geo.nx) return;
+    update_vec<R, COLL, V, NT, TURB>(src, dst, geo, w, raw, x0, y);
+}
+
+// ---- two steps per launch (see update_tile2 in lbm_device.hpp) --------------------------------------
+constexpr int TB_F = 4;      // cells within F of a wall / slab edge are advanced by single steps (8 with four steps per launch)
+constexpr int TB_NT = 512;   // threads per tile
+// Tile shape (measured sweep, profiles/r01_logs/tb2.log, tb3.log): wide and short wins -- 62 vectors (248 fp32 / 124 fp64 cells)
+// x 6 rows: phase 1 is 8 rows x 64 vectors = exactly one vector cell per thread and one wave per 1-KiB row segment
+// (9 x 8 x 256 x 4 B = 72 KiB of LDS: two tiles per CU).  The row re-reads of the short tile are served by L2.
+// With the two Smagorinsky history planes: 30 vectors x 12 rows (11 x 14 x 128 x 4 B = 77 KiB).
+template <bool TURB> constexpr int tb_ty() { return TURB ? 12 : 6; }
+template <bool TURB> constexpr int tb_txv() { return TURB ? 30 : 62; }
+
+template <typename R, int COLL, bool TURB>
+__global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+                                                      Batch<R> bt, int xe, int ye, int ntx, int ntiles) {
+    LBM_BATCH_SELECT(blockIdx.y)
+    constexpr int V = 16 / (int)sizeof(R), TX = tb_txv<TURB>() * V, TY = tb_ty<TURB>();
+    __shared__ __align__(16) R lds[(TURB ? Q + 2 : Q) * (TY + 2) * (TX + 2 * V)];
+    int b = blockIdx.x;
+    const int per = ntiles >> 3;
+    if (b < (per << 3)) b = (b & 7) * per + (b >> 3);   // every XCD walks its own band of tile rows
+    update_tile2<R, COLL, V, TX, TY, TB_NT, TURB>(src, dst, geo, w, lds, TB_F + (b % ntx) * TX, TB_F + (b / ntx) * TY, xe, ye);
+}
+
+// All S frame passes of a multi-step in ONE launch.  The frame (width F) is cut into rectangles: segments of FR_L columns of the
+// top and bottom row strips, segments of FR_L rows of the left and right column strips; one workgroup per rectangle.  Pass i
+// (margin m = S - i) computes the rectangle grown by m cells in x and y (clipped to the lattice; the rows of a slab interface
+// grow m rows into the neighbour's rows of the deep halo), all of it inside the frame of width F + m, from the output of pass
+// i - 1 -- every cell a workgroup reads it has written itself one pass earlier, so workgroups never wait for each other; where
+// grown rectangles overlap, both workgroups write the same bits.  Each pass has its own scratch lattice (a ping-pong pair would
+// let a fast workgroup overwrite cells a slow neighbour still reads); the last pass writes lat[b].  Same per-cell operations as
+// S launches of k_step_frame.
+template <typename R>
+struct FramePtrs {
+    const R* src;    // state n
+    R* pass[5];      // output of pass 1 .. S (pass[S - 1] = the destination lattice)
+};
+
+template <typename R>
+__device__ __forceinline__ R* pass_ptr(const FramePtrs<R>& fp, int j) {   // (selects, not an indexed load: no private-memory copy)
+    return j == 0 ? fp.pass[0] : j == 1 ? fp.pass[1] : j == 2 ? fp.pass[2] : j == 3 ? fp.pass[3] : fp.pass[4];
+}
+
+// LDS bytes a workgroup of the fused frame passes may use (= the tile kernel's buffer)
+constexpr int FRAME_LDS_BYTES = 48 * 1024;
+
+template <typename R, int COLL, int SEM, bool TURB, int NT>
+__device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long boff, const Geo& geo, const Relax<R>& w, int F, int S,
+                                             int nsegx, int nsegy, int lo, int hi, int b, int FR_L, R* lds) {
+    int x0, x1, y0, y1;   // owned rectangle [x0, x1) x [y0, y1)
+    if (b < 2 * nsegx) {
+        const int seg = b % nsegx;
+        x0 = seg * FR_L; x1 = min(geo.nx, x0 + FR_L);
+        y0 = b < nsegx ? 0 : geo.ny - F; y1 = y0 + F;
+    } else {
+        b -= 2 * nsegx;
+        const int seg = b % nsegy;
+        y0 = F + seg * FR_L; y1 = min(geo.ny - F, y0 + FR_L);
+        x0 = b < nsegy ? 0 : geo.nx - F; x1 = x0 + F;
+    }
+    if (lds) {
+        // The output of the intermediate passes stays in LDS: a window = the rectangle of pass 1 plus a ring of one cell (ghost
+        // positions where wall cells park kept slots and densities), two buffers in turn.  Pass 1 reads the lattice, the last
+        // pass writes the lattice; every window entry a pass reads was written by the pass before (or is overwritten by a wall
+        // rule before use); the window is zeroed first so that such dead reads see numbers.
+        constexpr int NP = TURB ? Q + 2 : Q;
+        const int m1 = S - 1;
+        const int xa1 = max(0, x0 - m1), xb1 = min(geo.nx, x1 + m1);
+        const int ya1 = max(lo ? -m1 : 0, y0 - m1), yb1 = min(geo.ny + (hi ? m1 : 0), y1 + m1);
+        Window win;
+        win.x0 = xa1 - 1; win.y0 = ya1 - 1; win.pitch = xb1 - xa1 + 2; win.plane = win.pitch * (yb1 - ya1 + 2);
+        R* const buf0 = lds;
+        R* const buf1 = lds + NP * win.plane;
+        for (int t = threadIdx.x; t < 2 * NP * win.plane; t += NT) lds[t] = (R)0;
+        __syncthreads();
+        for (int i = 1; i <= S; ++i) {
+            const int m = S - i;
+            const int xa = max(0, x0 - m), xb = min(geo.nx, x1 + m);
+            const int ya = max(lo ? -m : 0, y0 - m), yb = min(geo.ny + (hi ? m : 0), y1 + m);
+            const int wx = xb - xa, n = wx * (yb - ya);
+            R* const wr = (i & 1) ? buf0 : buf1;
+            const R* const rd = (i & 1) ? buf1 : buf0;
+            if (i == 1) {
+                const R* src = fp.src + boff;
+                for (int t = threadIdx.x; t < n; t += NT)
+                    update_cell_a<R, COLL, SEM, TURB, Geo, Window>(src, geo, wr, win, geo, w, 0, xa + t % wx, ya + t / wx);
+            } else if (i < S) {
+                for (int t = threadIdx.x; t < n; t += NT)
+                    update_cell_a<R, COLL, SEM, TURB, Window, Window>(rd, win, wr, win, geo, w, 0, xa + t % wx, ya + t / wx);
+            } else {
+                R* dst = pass_ptr(fp, S - 1) + boff;
+                for (int t = threadIdx.x; t < n; t += NT)
+                    update_cell_a<R, COLL, SEM, TURB, Window, Geo>(rd, win, dst, geo, geo, w, 0, xa + t % wx, ya + t / wx);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    for (int i = 1; i <= S; ++i) {
+        const int m = S - i;
+        const int xa = max(0, x0 - m), xb = min(geo.nx, x1 + m);
+        const int ya = max(lo ? -m : 0, y0 - m), yb = min(geo.ny + (hi ? m : 0), y1 + m);
+        const int wx = xb - xa, n = wx * (yb - ya);
+        const R* src = (i == 1 ? fp.src : pass_ptr(fp, i - 2)) + boff;
+        R* dst = pass_ptr(fp, i - 1) + boff;
+        for (int t = threadIdx.x; t < n; t += NT) update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, 0, xa + t % wx, ya + t / wx);
+        __syncthreads();   // workgroup-scope release / acquire: the next pass reads what this one wrote (global memory)
+    }
+}
+
+template <typename R, int COLL, int SEM, bool TURB>
+__global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, Relax<R> w, Batch<R> bt, int F, int S, int nsegx, int nsegy,
+                                                     int lo, int hi, int seg, int use_lds) {
+    __shared__ __align__(16) R lds[FRAME_LDS_BYTES / sizeof(R)];
+    long long boff = 0;
+    if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
+    frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg, use_lds ? lds : nullptr);
+}
+
+// S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS.  The
+// occupancy floor of 4 waves per SIMD (<= 128 VGPRs) keeps two workgroups on a CU: the MRT / TRT + Smagorinsky variants would
+// otherwise take 132 and run one (perf22.log vs perf23.log: fp32 MRT turb 96 -> 115 GLUPS).  WIDE: region 32 vectors x 16 rows;
+// otherwise 16 vectors x 32 rows (less rim work, shorter row segments).  The tile is the region minus the rim: V cells
+// left and right, S - 1 rows above and below.  F = frame width (4; 8 for S = 4 in fp32).
+template <typename R, int COLL, int SEM, int S, bool WIDE, bool TURB>
+__global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w,
+                                                    Batch<R> bt, int F, int xe, int ye, int ntx, int ntiles, FramePtrs<R> fp, int nframe,
+                                                    int nsegx, int nsegy, int seg, int use_lds) {
+    constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
+    constexpr int RV = (S - 1 + V - 1) / V;        // rim vectors per side: 1, or 2 for fp64 beyond three steps
+    constexpr int TX = (PVC - 2 * RV) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * RV * V;
+    __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
+    if ((int)blockIdx.x < nframe) {                                         // read one element past their row
+        // A lone lattice: the first nframe workgroups of the launch do the S frame passes (frame_passes), the rest the tiles --
+        // one launch per S steps and no cross-stream dependency (between slabs the frame stays a launch of its own on the
+        // communication stream: nframe = 0).  The frame workgroups run S dependent passes and take the longest: they go first.
+        long long boff = 0;
+        if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
+        static_assert(sizeof(lds_raw) >= FRAME_LDS_BYTES, "frame window buffer");
+        frame_passes<R, COLL, SEM, TURB, 512>(fp, boff, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg, use_lds ? lds_raw : nullptr);
+        return;
+    }
+    LBM_BATCH_SELECT(blockIdx.y)
+    int b = blockIdx.x - nframe;
+    const int per = ntiles >> 3;
+    if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
+    update_tile_inplace<R, COLL, V, TX, TY, S, TURB, RV>(src, dst, geo, w, lds_raw + V, F + (b % ntx) * TX, F + (b / ntx) * TY, xe, ye);
+}
+
+// One single step on the frame of width W around the slab: rows [0, W) and [ny-W, ny) in full, columns [0, W) and
+// [nx-W, nx) of the rows in between.  One thread per cell, complete wall / kept-slot logic.
+// elo / ehi: the row strips start elo rows above row 0 / end ehi rows below row ny - 1, in the ghost rows that hold the
+// neighbour slab's rows (deep halo: the passes of a multi-step recompute a shrinking band of the neighbour's rows instead of
+// exchanging one row per pass).
+template <typename R, int COLL, int SEM, bool TURB>
+__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, Batch<R> bt, int W, int elo, int ehi) {
+    LBM_BATCH_SELECT(blockIdx.y)
+    const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long ntop = (long long)(W + elo) * geo.nx, nbot = (long long)(W + ehi) * geo.nx;
+    const long long nrow = ntop + nbot, ncol = 2LL * W * (geo.ny - 2 * W);
+    int x, y;
+    if (t < nrow) {
+        const int o = (int)(t < ntop ? t : t - ntop);
+        x = o % geo.nx;
+        y = (t < ntop ? -elo : geo.ny - W) + o / geo.nx;
+    } else if (t < nrow + ncol) {
+        const long long u = t - nrow, half = (long long)W * (geo.ny - 2 * W);
+        const int strip = (int)(u / half), o = (int)(u % half);
+        y = W + o / W;
+        x = (strip == 0 ? 0 : geo.nx - W) + o % W;
+    } else {
+        return;
+    }
+    update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, 0, x, y);
+}
+
+// init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
+template <typename R>
+__global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB, int turb, long long bstride) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    lat += blockIdx.z * bstride;
+    R fe[Q];
+    equ<R>((R)1, (geo.y0 + y) == 0 ? uLB : (R)0, (R)0, fe);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) lat[k * geo.plane + geo.at(x, y)] = fe[k];
+    if (turb) {   // Smagorinsky history: feq_g starts as a copy of fin, rho_g as 1 (MRT_GPU.py:324-326)
+        lat[K_QEQ * geo.plane + geo.at(x, y)] = diag_flux<R>(fe);
+        lat[K_RHO * geo.plane + geo.at(x, y)] = (R)1;
+    }
+}
+
+// staging (reference host layout, [9][nx][ny_local], y fastest) -> raw lattice
+template <typename R>
+__global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* __restrict__ lat, Geo geo, R uLB, int turb, long long bstride) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    const long long n = (long long)geo.nx * geo.ny;
+    lat += blockIdx.z * bstride;
+    stage += blockIdx.z * (Q * n);
+    R g[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        g[k] = stage[k * n + (long long)x * geo.ny + y];
+        lat[k * geo.plane + geo.at(x, y)] = g[k];
+    }
+    if (turb) {   // history := equilibrium / density of the uploaded state (there is no "previous step")
+        R rho, ux, uy, fe[Q];
+        macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
+        equ<R>(rho, ux, uy, fe);
+        lat[K_QEQ * geo.plane + geo.at(x, y)] = diag_flux<R>(fe);
+        lat[K_RHO * geo.plane + geo.at(x, y)] = rho;
+    }
+}
+
+// lattice -> staging: current populations (post stream + wall rules) in host layout
+template <typename R, int SEM>
+__global__ __launch_bounds__(BLK) void k_export_fin(const R* __restrict__ src, Geo geo, int raw, R uLB,
+                                                    R* __restrict__ stage, long long bstride) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    const long long n = (long long)geo.nx * geo.ny;
+    src += blockIdx.z * bstride;
+    stage += blockIdx.z * (Q * n);
+    R g[Q];
+    gather<R, SEM>(src, geo, raw, uLB, x, y, g);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) stage[k * n + (long long)x * geo.ny + y] = g[k];
+}
+
+// lattice -> staging: macroscopic fields (with wall overrides) of the populations gathered
+// from `src`; stage = [ux | uy | rho], each [nx][ny_local]
+template <typename R, int SEM>
+__global__ __launch_bounds__(BLK) void k_export_macro(const R* __restrict__ src, Geo geo, int raw, R uLB,
+                                                      R* __restrict__ stage, long long bstride) {
+    const int x = blockIdx.x * BLK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= geo.nx) return;
+    const long long n = (long long)geo.nx * geo.ny;
+    src += blockIdx.z * bstride;
+    stage += blockIdx.z * (3 * n);
+    R g[Q], rho, ux, uy;
+    gather<R, SEM>(src, geo, raw, uLB, x, y, g);
+    macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
+    const long long o = (long long)x * geo.ny + y;
+    stage[o] = ux;
+    stage[n + o] = uy;
+    stage[2 * n + o] = rho;
+}
+
+
