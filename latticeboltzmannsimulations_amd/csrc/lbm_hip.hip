@@ -714,7 +714,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // measured (profiles/r01_logs/perf37.log, perf38.log): one launch per unit instead of S + 1 and no cross-stream dependency:
         // 4096^2 fp32 278 -> 294 GLUPS, 1024^2 fp64 67 -> 91, 1024^2 fp32 96 -> 135; a batch of 64 x 384^2 loses 5 % (its many
         // short frame workgroups do better as separate small launches), so batches keep one launch per pass
-        c->frame_fused = !(ff && std::atoi(ff) == 0) && c->batch == 1;
+        c->frame_fused = !(ff && std::atoi(ff) == 0) && (c->batch == 1 || (ff && std::atoi(ff) == 2));   // (2: also for batches, A/B)
         // cells of the frame per workgroup (perf43.log): short segments finish a pass in one sweep of the workgroup and suit
         // lattices whose launch is over when the frame chain is (160^2: 4.1 us per step with 16, 6.3 with 64); long ones compute
         // less overlap and suit large lattices (2048^2: 244 GLUPS with 64, 215 with 16)
