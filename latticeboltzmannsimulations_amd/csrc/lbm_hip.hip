@@ -213,9 +213,11 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
-        const long long cells = (2LL * W + elo + ehi) * c->geo.nx + 2LL * W * (c->geo.ny - 2 * W);
+        constexpr int V = 16 / (int)sizeof(R);
+        const int vec_rows = VT::SEM == SEM_GPU && c->use_vec && c->geo.nx % V == 0 ? 1 : 0;   // row strips by vector cells
+        const long long cells = (2LL * W + elo + ehi) * (vec_rows ? c->geo.nx / V : c->geo.nx) + 2LL * W * (c->geo.ny - 2 * W);
         hipLaunchKernelGGL((k_step_frame<R, VT::COLL, VT::SEM, VT::TURB>), dim3((unsigned)((cells + BLK - 1) / BLK), c->batch), dim3(BLK), 0, s,
-                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), W, elo, ehi);
+                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), W, elo, ehi, vec_rows);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;

@@ -220,24 +220,43 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
 // neighbour slab's rows (deep halo: the passes of a multi-step recompute a shrinking band of the neighbour's rows instead of
 // exchanging one row per pass).
 template <typename R, int COLL, int SEM, bool TURB>
-__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, Batch<R> bt, int W, int elo, int ehi) {
+__global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, Batch<R> bt, int W, int elo, int ehi,
+                                                    int vec_rows) {
     LBM_BATCH_SELECT(blockIdx.y)
-    const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
-    const long long ntop = (long long)(W + elo) * geo.nx, nbot = (long long)(W + ehi) * geo.nx;
-    const long long nrow = ntop + nbot, ncol = 2LL * W * (geo.ny - 2 * W);
+    long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long ncol = 2LL * W * (geo.ny - 2 * W);
     int x, y;
-    if (t < nrow) {
-        const int o = (int)(t < ntop ? t : t - ntop);
-        x = o % geo.nx;
-        y = (t < ntop ? -elo : geo.ny - W) + o / geo.nx;
-    } else if (t < nrow + ncol) {
-        const long long u = t - nrow, half = (long long)W * (geo.ny - 2 * W);
-        const int strip = (int)(u / half), o = (int)(u % half);
-        y = W + o / W;
-        x = (strip == 0 ? 0 : geo.nx - W) + o % W;
+    if (SEM == SEM_GPU && vec_rows) {
+        // row strips by vector cells (16 B per access, as k_step_vec: side walls in-line, lid / bottom-wall rows cell by cell)
+        constexpr int V = 16 / (int)sizeof(R);
+        const int nvx = geo.nx / V;
+        const long long ntop = (long long)(W + elo) * nvx, nbot = (long long)(W + ehi) * nvx;
+        if (t < ntop + nbot) {
+            const int o = (int)(t < ntop ? t : t - ntop);
+            const int x0 = (o % nvx) * V, yv = (t < ntop ? -elo : geo.ny - W) + o / nvx, gy = geo.y0 + yv;
+            if (gy == 0 || gy == geo.NY - 1) {
+#pragma unroll 1
+                for (int c = 0; c < V; ++c) update_cell<R, COLL, SEM_GPU, TURB>(src, dst, geo, w, 0, x0 + c, yv);
+            } else {
+                update_vec<R, COLL, V, false, TURB>(src, dst, geo, w, 0, x0, yv);
+            }
+            return;
+        }
+        t -= ntop + nbot;
     } else {
-        return;
+        const long long ntop = (long long)(W + elo) * geo.nx, nbot = (long long)(W + ehi) * geo.nx;
+        if (t < ntop + nbot) {
+            const int o = (int)(t < ntop ? t : t - ntop);
+            update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, 0, o % geo.nx, (t < ntop ? -elo : geo.ny - W) + o / geo.nx);
+            return;
+        }
+        t -= ntop + nbot;
     }
+    if (t >= ncol) return;
+    const long long half = (long long)W * (geo.ny - 2 * W);
+    const int strip = (int)(t / half), o = (int)(t % half);
+    y = W + o / W;
+    x = (strip == 0 ? 0 : geo.nx - W) + o % W;
     update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, 0, x, y);
 }
 

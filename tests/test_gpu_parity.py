@@ -140,6 +140,18 @@ def test_two_and_three_steps_per_launch_agree(monkeypatch, dtype):
         with CavitySolver(260, 71, 400.0, RT=coll, semantics=sem, dtype=dtype, kernel="tb") as s:
             s.step(33)
             same(s, o, f"four steps {sem} {coll}")
+    # the other routes of the frame passes: one launch per pass on the second stream (row strips by vector cells), and the
+    # fused passes through scratch lattices instead of LDS windows; segment lengths that do / do not fit the LDS budget
+    o = CavityOracleC(260, 131, 400.0, semantics="mrt_gpu", collision="MRT", dtype=dtype).step(27)
+    monkeypatch.delenv("LBM_TB_STEPS")
+    for env in ({"LBM_FRAME_FUSED": "0"}, {"LBM_FRAME_LDS": "0"}, {"LBM_FRAME_SEG": "64"}, {"LBM_FRAME_SEG": "8"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with CavitySolver(260, 131, 400.0, RT="MRT", dtype=dtype, kernel="tb") as s:
+            s.step(27)
+            same(s, o, f"{env}")
+        for k in env:
+            monkeypatch.delenv(k)
     # with the Smagorinsky closure: two-phase kernel (history through LDS) and in-place kernel (history in registers)
     o = CavityOracleC(132, 99, 5000.0, semantics="mrt_gpu", collision="MRT", dtype=dtype, turb=1).step(29)
     for steps in ("2", "3", "4", "5"):
