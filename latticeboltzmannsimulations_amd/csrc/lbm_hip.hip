@@ -589,9 +589,13 @@ int stage_to_host(lbm_ctx* c, const void* stage, void* host, int host_dtype, int
     return LBM_OK;
 }
 
+// grid of the host-layout <-> lattice kernels: tiles of trx<R>() columns x 32 rows
+template <typename R>
+dim3 grid_tiles(const lbm_ctx* c) { return dim3((c->geo.nx + trx<R>() - 1) / trx<R>(), (c->geo.ny + 31) / 32, c->batch); }
+
 template <typename R>
 int export_fin_t(lbm_ctx* c) {
-    const dim3 g = grid_rows(c, c->geo.ny);
+    const dim3 g = grid_tiles<R>(c);
     const R* src = (const R*)c->lat[c->cur];
     if (c->p.semantics == LBM_SEM_MRT_PY)
         hipLaunchKernelGGL((k_export_fin<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[c->cur], (R)c->p.uLB, (R*)c->stage, c->bstride);
@@ -603,7 +607,7 @@ int export_fin_t(lbm_ctx* c) {
 
 template <typename R>
 int export_macro_t(lbm_ctx* c) {
-    const dim3 g = grid_rows(c, c->geo.ny);
+    const dim3 g = grid_tiles<R>(c);
     // the fields of the LAST iteration are the moments of the state that iteration started
     // from, i.e. of the previous lattice (still intact: a step only reads it)
     const int which = c->nsteps > 0 ? (c->cur ^ 1) : c->cur;
@@ -809,11 +813,10 @@ int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
     rc = host_to_stage(c, fin_host, host_dtype, Q * c->batch);   // [B][9][nx][ny] is B * 9 planes
     if (rc) return rc;
     c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_rows = 0;
-    const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
-        hipLaunchKernelGGL((k_import<float>), g, dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
+        hipLaunchKernelGGL((k_import<float>), grid_tiles<float>(c), dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
     else
-        hipLaunchKernelGGL((k_import<double>), g, dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb, c->bstride);
+        hipLaunchKernelGGL((k_import<double>), grid_tiles<double>(c), dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb, c->bstride);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->s_compute));
     return LBM_OK;

@@ -277,27 +277,46 @@ __global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uL
     }
 }
 
-// staging (reference host layout, [9][nx][ny_local], y fastest) -> raw lattice
+// ---- host layout <-> lattice ---------------------------------------------------------------------------------------------
+// The staging buffers hold the reference's host layout ([plane][nx][ny_local], y fastest); the lattice is x fastest.  Each
+// workgroup moves a tile of TRX columns x 32 rows through LDS, so that both sides are accessed along their fast axis.
+template <typename R> constexpr int trx() { return sizeof(R) == 4 ? 32 : 16; }   // 9 planes x TRX x 33 reals = 38 KiB of LDS
+
+// staging -> raw lattice
 template <typename R>
 __global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* __restrict__ lat, Geo geo, R uLB, int turb, long long bstride) {
-    const int x = blockIdx.x * BLK + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= geo.nx) return;
+    constexpr int TRX = trx<R>(), RY = BLK / TRX;
+    __shared__ R t[Q][TRX][33];
     const long long n = (long long)geo.nx * geo.ny;
     lat += blockIdx.z * bstride;
     stage += blockIdx.z * (Q * n);
-    R g[Q];
+    const int x0 = blockIdx.x * TRX, y0 = blockIdx.y * 32;
+    {   // read along y
+        const int yy = threadIdx.x & 31, xb = threadIdx.x >> 5;
+        for (int xx = xb; xx < TRX; xx += BLK / 32)
+            if (x0 + xx < geo.nx && y0 + yy < geo.ny) {
 #pragma unroll
-    for (int k = 0; k < Q; ++k) {
-        g[k] = stage[k * n + (long long)x * geo.ny + y];
-        lat[k * geo.plane + geo.at(x, y)] = g[k];
+                for (int k = 0; k < Q; ++k) t[k][xx][yy] = stage[k * n + (long long)(x0 + xx) * geo.ny + y0 + yy];
+            }
     }
-    if (turb) {   // history := equilibrium / density of the uploaded state (there is no "previous step")
-        R rho, ux, uy, fe[Q];
-        macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
-        equ<R>(rho, ux, uy, fe);
-        lat[K_QEQ * geo.plane + geo.at(x, y)] = diag_flux<R>(fe);
-        lat[K_RHO * geo.plane + geo.at(x, y)] = rho;
+    __syncthreads();
+    const int tx = threadIdx.x % TRX, x = x0 + tx;
+    for (int ty = threadIdx.x / TRX; ty < 32; ty += RY) {   // write along x
+        const int y = y0 + ty;
+        if (x >= geo.nx || y >= geo.ny) continue;
+        R g[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            g[k] = t[k][tx][ty];
+            lat[k * geo.plane + geo.at(x, y)] = g[k];
+        }
+        if (turb) {   // history := equilibrium / density of the uploaded state (there is no "previous step")
+            R rho, ux, uy, fe[Q];
+            macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
+            equ<R>(rho, ux, uy, fe);
+            lat[K_QEQ * geo.plane + geo.at(x, y)] = diag_flux<R>(fe);
+            lat[K_RHO * geo.plane + geo.at(x, y)] = rho;
+        }
     }
 }
 
@@ -305,16 +324,28 @@ __global__ __launch_bounds__(BLK) void k_import(const R* __restrict__ stage, R* 
 template <typename R, int SEM>
 __global__ __launch_bounds__(BLK) void k_export_fin(const R* __restrict__ src, Geo geo, int raw, R uLB,
                                                     R* __restrict__ stage, long long bstride) {
-    const int x = blockIdx.x * BLK + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= geo.nx) return;
+    constexpr int TRX = trx<R>(), RY = BLK / TRX;
+    __shared__ R t[Q][TRX][33];
     const long long n = (long long)geo.nx * geo.ny;
     src += blockIdx.z * bstride;
     stage += blockIdx.z * (Q * n);
-    R g[Q];
-    gather<R, SEM>(src, geo, raw, uLB, x, y, g);
+    const int x0 = blockIdx.x * TRX, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x % TRX, x = x0 + tx;
+    for (int ty = threadIdx.x / TRX; ty < 32; ty += RY) {   // gather along x
+        const int y = y0 + ty;
+        if (x >= geo.nx || y >= geo.ny) continue;
+        R g[Q];
+        gather<R, SEM>(src, geo, raw, uLB, x, y, g);
 #pragma unroll
-    for (int k = 0; k < Q; ++k) stage[k * n + (long long)x * geo.ny + y] = g[k];
+        for (int k = 0; k < Q; ++k) t[k][tx][ty] = g[k];
+    }
+    __syncthreads();
+    const int yy = threadIdx.x & 31, xb = threadIdx.x >> 5;
+    for (int xx = xb; xx < TRX; xx += BLK / 32)              // write along y
+        if (x0 + xx < geo.nx && y0 + yy < geo.ny) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) stage[k * n + (long long)(x0 + xx) * geo.ny + y0 + yy] = t[k][xx][yy];
+        }
 }
 
 // lattice -> staging: macroscopic fields (with wall overrides) of the populations gathered
@@ -322,19 +353,30 @@ __global__ __launch_bounds__(BLK) void k_export_fin(const R* __restrict__ src, G
 template <typename R, int SEM>
 __global__ __launch_bounds__(BLK) void k_export_macro(const R* __restrict__ src, Geo geo, int raw, R uLB,
                                                       R* __restrict__ stage, long long bstride) {
-    const int x = blockIdx.x * BLK + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= geo.nx) return;
+    constexpr int TRX = trx<R>(), RY = BLK / TRX;
+    __shared__ R t[3][TRX][33];
     const long long n = (long long)geo.nx * geo.ny;
     src += blockIdx.z * bstride;
     stage += blockIdx.z * (3 * n);
-    R g[Q], rho, ux, uy;
-    gather<R, SEM>(src, geo, raw, uLB, x, y, g);
-    macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
-    const long long o = (long long)x * geo.ny + y;
-    stage[o] = ux;
-    stage[n + o] = uy;
-    stage[2 * n + o] = rho;
+    const int x0 = blockIdx.x * TRX, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x % TRX, x = x0 + tx;
+    for (int ty = threadIdx.x / TRX; ty < 32; ty += RY) {
+        const int y = y0 + ty;
+        if (x >= geo.nx || y >= geo.ny) continue;
+        R g[Q], rho, ux, uy;
+        gather<R, SEM>(src, geo, raw, uLB, x, y, g);
+        macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
+        t[0][tx][ty] = ux; t[1][tx][ty] = uy; t[2][tx][ty] = rho;
+    }
+    __syncthreads();
+    const int yy = threadIdx.x & 31, xb = threadIdx.x >> 5;
+    for (int xx = xb; xx < TRX; xx += BLK / 32)
+        if (x0 + xx < geo.nx && y0 + yy < geo.ny) {
+            const long long o = (long long)(x0 + xx) * geo.ny + y0 + yy;
+            stage[o] = t[0][xx][yy];
+            stage[n + o] = t[1][xx][yy];
+            stage[2 * n + o] = t[2][xx][yy];
+        }
 }
 
 
