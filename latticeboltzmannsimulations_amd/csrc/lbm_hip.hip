@@ -710,7 +710,11 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // fp64 (perf46.log; an x rim of two vectors from four steps on): the factored MRT operator S = 3 / 4 / 5 = 98 / 123 / 142 GLUPS
         // at 4096^2 (8192 x 1024: 91 / 109 / 129); the strict operator is arithmetic-bound (103 / 105 / 103)
         const int want64 = fast && p->collision == LBM_MRT ? 5 : 3;
-        const int want = ts ? std::atoi(ts) : (p->dtype == LBM_F32 ? want32 : want64);
+        // a lone small lattice is bound by the launch, not by arithmetic or bandwidth: more steps per launch whatever the operator
+        // (perf52.log, strict: 160^2 fp32 4.33 -> 4.13 us per step with five, fp64 5.02 -> 4.65 with four)
+        const bool small_lone = one_launch && (long long)p->nx * p->ny_local <= 512LL * 512;
+        const int want = ts ? std::atoi(ts) : small_lone ? (p->dtype == LBM_F32 ? 5 : std::max(4, want64))
+                                                         : (p->dtype == LBM_F32 ? want32 : want64);
         const bool deep_ok = p->nx >= 64 && p->ny_local >= 64;
         c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
         c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
