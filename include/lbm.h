@@ -155,7 +155,8 @@ int lbm_step_finish(lbm_ctx* c);
 /* uid_out: 128 bytes (ncclUniqueId) created on one rank and distributed by the caller
  * (e.g. torch.distributed broadcast).  After lbm_comm_init, lbm_step() exchanges halos with
  * rank-1 / rank+1 by ncclSend/ncclRecv on a second HIP stream, overlapped with the
- * interior rows. */
+ * interior rows: one row of three directions per single step; before a launch that advances S
+ * steps, the S complete rows next to each interface in one message per side (MRT_GPU semantics). */
 int lbm_comm_unique_id(void* uid_out128);
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128);
 /* Diagnostic for one-GPU machines: attaches a ONE-rank RCCL communicator and makes the slab its own
