@@ -103,6 +103,16 @@ def cpu_table():
     return rows
 
 
+def slab_of(config, scaling, world, rank):
+    """(global height, (first row, rows)) of rank `rank`: weak scaling gives every rank the N = 1 workload as a y-slab of a
+    lattice `world` times as tall; strong scaling cuts the N = 1 lattice into `world` slabs."""
+    from latticeboltzmannsimulations_amd.slab import partition_rows
+    ny_gpu = CONFIGS[config][1]
+    if scaling == "weak":
+        return ny_gpu * world, (rank * ny_gpu, ny_gpu)
+    return ny_gpu, partition_rows(ny_gpu, world)[rank]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-table", action="store_true", help="time the CPU restatements only (SURVEY 8d table) and exit")
@@ -135,7 +145,7 @@ def main():
     import torch                      # plumbing: process group, barrier, device sync
     import torch.distributed as dist
     from latticeboltzmannsimulations_amd import CavitySolver
-    from latticeboltzmannsimulations_amd.slab import attach_rccl, partition_rows
+    from latticeboltzmannsimulations_amd.slab import attach_rccl
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible)")
@@ -149,12 +159,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     nx, ny_gpu, Re, dtype, RT, sem, label = CONFIGS[a.config]
-    if a.scaling == "weak":
-        NY = ny_gpu * world
-        rows = (rank * ny_gpu, ny_gpu)
-    else:
-        NY = ny_gpu
-        rows = partition_rows(NY, world)[rank]
+    NY, rows = slab_of(a.config, a.scaling, world, rank)
     solver = CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev,
                           rows=rows if world > 1 else None, kernel=a.kernel, arith=a.arith)
     if world > 1:

@@ -42,3 +42,17 @@ def test_traffic_table_has_the_default_bench_entry():
     # several steps per launch move less than the algorithmic 18 words per update; one step per launch moves about that
     assert t["c3:1:auto:fast"]["hbm_bytes_per_step"] < 0.3 * t["c3:1:auto:fast"]["algorithmic_bytes_per_step"]
     assert 0.95 < t["c3:1:vec:strict"]["hbm_bytes_per_step"] / (4096 * 4096 * 72) < 1.1
+
+
+def test_slab_plan_of_the_multi_gpu_bench():
+    """bench.py --gpus N: weak scaling = N slabs of the N = 1 workload stacked in y; strong scaling = the N = 1 lattice cut."""
+    for world in (1, 2, 4, 8):
+        rows = [bench.slab_of("c3", "weak", world, r) for r in range(world)]
+        assert all(NY == 4096 * world for NY, _ in rows)
+        assert [r[1] for r in rows] == [(4096 * i, 4096) for i in range(world)]
+        rows = [bench.slab_of("c3", "strong", world, r) for r in range(world)]
+        assert all(NY == 4096 for NY, _ in rows)
+        assert rows[0][1][0] == 0 and sum(r[1][1] for r in rows) == 4096
+        assert all(rows[i][1][0] + rows[i][1][1] == rows[i + 1][1][0] for i in range(world - 1))
+    NY, (y0, n) = bench.slab_of("c5", "weak", 8, 7)
+    assert (NY, y0, n) == (16384, 14336, 2048)                   # BASELINE configs[4]: 16384 x 16384 over 8 GPUs
