@@ -709,7 +709,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const int want32 = fast ? (p->collision == LBM_TRT ? 4 : 5) : (trt_turb ? 3 : 4);
         // fp64 (perf46.log; an x rim of two vectors from four steps on): the factored MRT operator S = 3 / 4 / 5 = 98 / 123 / 142 GLUPS
         // at 4096^2 (8192 x 1024: 91 / 109 / 129); the strict operator is arithmetic-bound (103 / 105 / 103)
-        const int want64 = fast && p->collision == LBM_MRT ? 5 : 3;
+        // (SRT + closure fp64: 81 / 88 / 88 GLUPS)
+        const int want64 = p->collision == LBM_MRT ? (fast ? 5 : 3) : 4;
         // a lone small lattice is bound by the launch, not by arithmetic or bandwidth: more steps per launch whatever the operator
         // (perf52.log, strict: 160^2 fp32 4.33 -> 4.13 us per step with five, fp64 5.02 -> 4.65 with four)
         const bool small_lone = one_launch && (long long)p->nx * p->ny_local <= 512LL * 512;
