@@ -117,8 +117,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-table", action="store_true", help="time the CPU restatements only (SURVEY 8d table) and exit")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
-    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--arith", choices=["fast", "strict"], default="fast",
