@@ -67,8 +67,9 @@ typedef struct lbm_params {
                             leading [B] axis.  Not combinable with slabs. */
     int32_t arith;       /* LBM_ARITH_STRICT (0, default): every operation in the reference's order, results bit-identical to
                             the CPU restatement in oracle/.  LBM_ARITH_FAST: the MRT operator in an algebraically identical
-                            factored form with fused multiply-adds (about half the arithmetic); in fp32 also u = j * rcp(rho)
-                            and the Smagorinsky closure's divisions / square root by the 1-ulp hardware instructions.
+                            factored form with fused multiply-adds (about half the arithmetic); u = j * rcp(rho) and the
+                            Smagorinsky closure's divisions / square root by the hardware's reciprocal / square-root
+                            instructions (fp32: 1 ulp; fp64: refined by Newton steps).
                             Results agree with the strict form to rounding, not bit for bit.  MRT_GPU semantics only
                             (with LBM_SEM_MRT_PY the strict form is used). */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */

@@ -23,8 +23,8 @@ enum { SEM_PY = 0, SEM_GPU = 1 };
 enum { C_SRT = 0, C_TRT = 1, C_MRT = 2,
        // lbm_params.arith = LBM_ARITH_FAST: not the reference's operation order / rounding --
        C_MRT_FAST = 3,     // the MRT operator in factored form with fused multiply-adds
-       C_SRT_FAST = 4,     // SRT / TRT as in the strict form, but (fp32) u = j * rcp(rho) and the closure's divisions and
-       C_TRT_FAST = 5 };   // square root by the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 instead of the IEEE sequences
+       C_SRT_FAST = 4,     // SRT / TRT as in the strict form, but u = j * rcp(rho) and the closure's divisions and square root by
+       C_TRT_FAST = 5 };   // v_rcp_f32 / v_sqrt_f32 (1 ulp; fp64: v_rcp_f64 / v_rsq_f64 + Newton) instead of the IEEE sequences
 constexpr bool coll_is_mrt(int c) { return c == C_MRT || c == C_MRT_FAST; }
 constexpr bool coll_is_fast(int c) { return c >= C_MRT_FAST; }
 
@@ -83,12 +83,28 @@ __device__ __forceinline__ R weight(int k) {
 // a / b and sqrt: IEEE-exact, or (FAST, fp32 only) by v_rcp_f32 / v_sqrt_f32 (1 ulp) -- the same instruction per lane in the
 // scalar and the packed form, so every kernel variant still produces the same bits
 template <bool FAST> __device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
-template <bool FAST> __device__ __forceinline__ double div_(double a, double b) { return a / b; }
+// fp64: v_rcp_f64 / v_rsq_f64 (about 2^-26) refined by two Newton steps (error far below one ulp of the iterate; the product with
+// `a` rounds once more) instead of the IEEE sequences of ~25 instructions
+__device__ __forceinline__ double rcp_nr(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return r;
+}
+template <bool FAST> __device__ __forceinline__ double div_(double a, double b) { return FAST ? a * rcp_nr(b) : a / b; }
 template <bool FAST> __device__ __forceinline__ f32x2 div_(f32x2 a, f32x2 b) {
     return FAST ? a * f32x2{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)} : a / b;
 }
 template <bool FAST> __device__ __forceinline__ float sqrt_(float a) { return FAST ? __builtin_amdgcn_sqrtf(a) : sqrtf(a); }
-template <bool FAST> __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
+template <bool FAST> __device__ __forceinline__ double sqrt_(double a) {
+    if (!FAST) return sqrt(a);
+    if (a <= 0.0) return 0.0;                        // (the closure's argument is tau0^2 + ... > 0)
+    double y = __builtin_amdgcn_rsq(a);              // 1 / sqrt(a), ~2^-26
+    y = y * __builtin_fma(-0.5 * a * y, y, 1.5);     // Newton on 1 / sqrt
+    y = y * __builtin_fma(-0.5 * a * y, y, 1.5);
+    const double g = a * y;                          // sqrt(a), then one correction step
+    return __builtin_fma(__builtin_fma(-g, g, a), 0.5 * y, g);
+}
 template <bool FAST> __device__ __forceinline__ f32x2 sqrt_(f32x2 a) {
     return FAST ? f32x2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)} : f32x2{sqrtf(a.x), sqrtf(a.y)};
 }
