@@ -40,7 +40,9 @@ enum { LBM_SEM_MRT_PY = 0, LBM_SEM_MRT_GPU = 1 };       /* streaming windows + w
 enum { LBM_KERNEL_AUTO = 0,      /* fastest applicable: TB (lattices from 64 x 64 cells), else VEC, else GENERIC */
        LBM_KERNEL_GENERIC = 1,   /* one step per launch, one thread per cell (all semantics) */
        LBM_KERNEL_VEC = 2,       /* one step per launch, 16 B per access (MRT_GPU semantics) */
-       LBM_KERNEL_TB = 3 };      /* several (3 .. 5) time steps per launch: tiles through LDS + the wall frame */
+       LBM_KERNEL_TB = 3,        /* several (3 .. 5) time steps per launch: tiles through LDS + the wall frame */
+       LBM_KERNEL_PUSH = 4 };    /* the reference's own scheme for A/B: collide-and-push into a persistent second array, then a
+                                    wall-rule + copy kernel (funRT + funBC, MRT_GPU.py:339-698); one whole lattice, no closure */
 enum { LBM_LAYOUT_AUTO = 0, LBM_LAYOUT_PLANES = 1, LBM_LAYOUT_ROWS = 2 }; /* device arrays: [k][y][x] or [y][k][x] */
 enum { LBM_ARITH_STRICT = 0, LBM_ARITH_FAST = 1 };
 enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour towards smaller / larger y */

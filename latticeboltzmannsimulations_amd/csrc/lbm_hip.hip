@@ -56,6 +56,7 @@ struct lbm_ctx {
                                 // one-neighbour code paths of the first / last rank; the other side then reads its never-written ghost rows)
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
+    bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
     bool use_tb = false;        // several steps per launch (temporal blocking)
     int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel)
     int tb_f = TB_F;            // frame width
@@ -289,7 +290,7 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
 
 void finish_step(lbm_ctx* c) {
     c->cur ^= 1;
-    c->raw[c->cur] = 0;
+    c->raw[c->cur] = c->push ? 1 : 0;   // (push scheme: the lattices hold plain populations, nothing to stream at read time)
     c->nsteps += 1;
 }
 
@@ -524,7 +525,37 @@ int unit_steps(const lbm_ctx* c, int left, bool raw) {
     return 1;
 }
 
+// One step of the push scheme: collide-and-push lat[cur] -> ftemp (lat[2]); wall rules on ftemp + copy -> lat[cur ^ 1].
+int push_step(lbm_ctx* c) {
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
+        const dim3 g = grid_rows(c, c->geo.ny);
+        hipLaunchKernelGGL((k_push_collide<R, VT::COLL, VT::SEM>), g, dim3(BLK), 0, c->s_compute, (const R*)c->lat[c->cur], (R*)c->lat[2], c->geo,
+                           relax_of<R>(c->p));
+        hipLaunchKernelGGL((k_push_bc<R, VT::COLL, VT::SEM>), g, dim3(BLK), 0, c->s_compute, (const R*)c->lat[c->cur], (R*)c->lat[2],
+                           (R*)c->lat[c->cur ^ 1], c->geo, (R)c->p.uLB);
+    });
+    HIP_TRY(c, hipGetLastError());
+    finish_step(c);
+    return LBM_OK;
+}
+
+// ftemp starts as a copy of fin (MRT_GPU.py:324)
+int push_reset(lbm_ctx* c) {
+    if (!c->push) return LBM_OK;
+    HIP_TRY(c, hipMemcpyAsync(c->lat[2], c->lat[0], (size_t)c->bstride * c->es, hipMemcpyDeviceToDevice, c->s_compute));
+    return LBM_OK;
+}
+
 int step_many(lbm_ctx* c, int nsteps) {
+    if (c->push) {
+        for (int i = 0; i < nsteps; ++i) {
+            int rc = push_step(c);
+            if (rc) return rc;
+        }
+        return LBM_OK;
+    }
     bool comm_used = false;
     if (c->use_tb || c->nranks > 1 || c->loopback)   // (a lone slab stepping one step per launch uses one stream, no events)
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier calls)
@@ -649,7 +680,9 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return bail("bad semantics");
     if (p->turb != 0 && p->turb != 1) return bail("turb must be 0 or 1");
     if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return bail("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
-    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_TB) return bail("bad kernel variant");
+    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_PUSH) return bail("bad kernel variant");
+    if (p->kernel == LBM_KERNEL_PUSH && (p->turb || p->batch > 1 || p->y0 != 0 || p->ny_local != p->ny))
+        return bail("kernel = PUSH (the reference's two-launch scheme, for A/B) takes one whole lattice without the closure");
     if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
     if (p->batch < 0 || p->batch > 65535) return bail("batch must be 0 .. 65535");
     if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return bail("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
@@ -684,7 +717,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const int V = 16 / c->es;
         const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;
         if (p->kernel == LBM_KERNEL_VEC && !can_vec) return (delete c, bail("kernel = VEC needs MRT_GPU semantics and nx % (16 / sizeof(real)) == 0"));
-        c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC;
+        c->push = p->kernel == LBM_KERNEL_PUSH;
+        c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC && !c->push;
         const bool can_tb = p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
         if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
         // measured crossover: with one launch per frame pass (batches, LBM_FRAME_FUSED=0) a multi-step pays from ~768^2 cells
@@ -756,7 +790,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
     // scratch lattices of the frame passes: one per pass but the last (the fused frame kernel), at least the ping-pong pair
-    for (int i = 0; i < (c->use_tb ? (c->tb_steps == 2 ? 3 : 2 + std::max(2, c->tb_steps - 1)) : 2); ++i) {
+    for (int i = 0; i < (c->use_tb ? (c->tb_steps == 2 ? 3 : 2 + std::max(2, c->tb_steps - 1)) : (c->push ? 3 : 2)); ++i) {
         if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
         // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
         if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
@@ -805,7 +839,7 @@ int lbm_init_equilibrium(lbm_ctx* c) {
     else
         hipLaunchKernelGGL((k_init<double>), g, dim3(BLK), 0, c->s_compute, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb, c->bstride);
     HIP_TRY(c, hipGetLastError());
-    return LBM_OK;
+    return push_reset(c);
 }
 
 int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
@@ -823,6 +857,8 @@ int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
     else
         hipLaunchKernelGGL((k_import<double>), grid_tiles<double>(c), dim3(BLK), 0, c->s_compute, (const double*)c->stage, (double*)c->lat[0], c->geo, (double)c->p.uLB, c->p.turb, c->bstride);
     HIP_TRY(c, hipGetLastError());
+    rc = push_reset(c);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->s_compute));
     return LBM_OK;
 }
@@ -942,18 +978,21 @@ int lbm_halo_import(lbm_ctx* c, int side, const void* buf) {
 
 int lbm_step_edges(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
+    if (c->push) return fail(c, LBM_ERR_STATE, "the split-step calls do not apply to kernel = PUSH");
     HIP_TRY(c, hipSetDevice(c->p.device));
     return launch_rows(c, 0, c->geo.ny - 1, 2, c->s_compute);
 }
 
 int lbm_step_interior(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
+    if (c->push) return fail(c, LBM_ERR_STATE, "the split-step calls do not apply to kernel = PUSH");
     HIP_TRY(c, hipSetDevice(c->p.device));
     return launch_rows(c, 1, 1, c->geo.ny - 2, c->s_compute);
 }
 
 int lbm_step_finish(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
+    if (c->push) return fail(c, LBM_ERR_STATE, "the split-step calls do not apply to kernel = PUSH");
     finish_step(c);
     return LBM_OK;
 }
@@ -971,7 +1010,7 @@ int lbm_comm_unique_id(void* uid_out128) {
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     if (!c || !uid128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, LBM_ERR_INVALID, "lbm_comm_init: bad argument");
     if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
-    if (c->batch > 1) return fail(c, LBM_ERR_STATE, "a batch of lattices cannot be slab-decomposed");
+    if (c->batch > 1 || c->push) return fail(c, LBM_ERR_STATE, "a batch of lattices / kernel = PUSH cannot be slab-decomposed");
     if (!rccl().ok) return fail(c, LBM_ERR_COMM, rccl().err);
     HIP_TRY(c, hipSetDevice(c->p.device));
     ncclUniqueId id;

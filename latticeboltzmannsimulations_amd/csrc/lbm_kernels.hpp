@@ -260,6 +260,55 @@ __global__ __launch_bounds__(BLK) void k_step_frame(const R* __restrict__ src, R
     update_cell<R, COLL, SEM, TURB>(src, dst, geo, w, 0, x, y);
 }
 
+// ---- the reference's own scheme, for A/B against the fused pull kernels (LBM_KERNEL_PUSH) ---------------------------------------
+// Two launches per step, as funRT + funBC (MRT_GPU.py:339-420,536-660 / 665-698): `fin` holds the populations a step starts
+// from; k_push_collide relaxes every cell and PUSHES slot k into the persistent array `ftemp` at (x + cx, y - cy) if that cell
+// streams it (slots outside their window keep what ftemp held); k_push_bc applies the wall rules to ftemp in place, with the
+// equilibrium of the state the step started from, and copies ftemp into the next `fin`.  About 49 words per cell and step
+// against the 18 of the fused pull kernel.  Same per-cell operators, so the results are bit-identical to the pull kernels.
+template <typename R, int COLL, int SEM>
+__global__ __launch_bounds__(BLK) void k_push_collide(const R* __restrict__ fin, R* __restrict__ ftemp, Geo geo, Relax<R> w) {
+    const int x = blockIdx.x * BLK + threadIdx.x, y = blockIdx.y;
+    if (x >= geo.nx) return;
+    const int X = geo.nx, Y = geo.NY, gy = geo.y0 + y;
+    R g[Q], rho, ux, uy, fe[Q], out[Q];
+    const long long me = geo.at(x, y);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) g[k] = fin[k * geo.plane + me];
+    macros<R, coll_is_fast(COLL)>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
+    equ<R>(rho, ux, uy, fe);
+    collide<R, COLL>(g, rho, fe, w, w.w_nu, out);
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int dx = x + cxk(k), dgy = gy - cyk(k);
+        if (dx >= 0 && dx < X && dgy >= 0 && dgy < Y && in_window<SEM>(k, dx, dgy, X, Y))
+            ftemp[k * geo.plane + geo.at(dx, y - cyk(k))] = out[k];
+    }
+}
+
+template <typename R, int COLL, int SEM>
+__global__ __launch_bounds__(BLK) void k_push_bc(const R* __restrict__ fin_old, R* __restrict__ ftemp, R* __restrict__ fin_new, Geo geo, R uLB) {
+    const int x = blockIdx.x * BLK + threadIdx.x, y = blockIdx.y;
+    if (x >= geo.nx) return;
+    const int X = geo.nx, Y = geo.NY, gy = geo.y0 + y;
+    const long long me = geo.at(x, y);
+    R g[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) g[k] = ftemp[k * geo.plane + me];
+    if (x == 0 || x == X - 1 || gy == 0 || gy == Y - 1) {
+        R f0[Q], rho, ux, uy, fe[Q];   // equilibrium of the state this step started from (feq_g written by funRT)
+#pragma unroll
+        for (int k = 0; k < Q; ++k) f0[k] = fin_old[k * geo.plane + me];
+        macros<R, coll_is_fast(COLL)>(f0, x, gy, X, Y, uLB, rho, ux, uy);
+        equ<R>(rho, ux, uy, fe);
+        wall_rules<R, SEM>(g, fe, x, gy, X, Y);
+#pragma unroll
+        for (int k = 0; k < Q; ++k) ftemp[k * geo.plane + me] = g[k];
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) fin_new[k * geo.plane + me] = g[k];
+}
+
 // init: raw populations = equ(rho = 1, u = (uLB on the global lid row, 0))  (MRT.py:260-268)
 template <typename R>
 __global__ __launch_bounds__(BLK) void k_init(R* __restrict__ lat, Geo geo, R uLB, int turb, long long bstride) {

@@ -11,7 +11,8 @@ from . import _lib as L
 _DT = {np.dtype(np.float32): L.LBM_F32, np.dtype(np.float64): L.LBM_F64}
 _COLL = {"SRT": L.LBM_SRT, "TRT": L.LBM_TRT, "MRT": L.LBM_MRT}
 _SEM = {"mrt_py": L.LBM_SEM_MRT_PY, "mrt_gpu": L.LBM_SEM_MRT_GPU}
-_KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC, "tb": L.LBM_KERNEL_TB}
+_KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC, "tb": L.LBM_KERNEL_TB,
+           "push": L.LBM_KERNEL_PUSH}
 _ARITH = {"strict": L.LBM_ARITH_STRICT, "fast": L.LBM_ARITH_FAST}
 _LAYOUT = {"auto": L.LBM_LAYOUT_AUTO, "planes": L.LBM_LAYOUT_PLANES, "rows": L.LBM_LAYOUT_ROWS}
 
@@ -38,7 +39,8 @@ class CavitySolver:
     dtype        : float32 (what MRT_GPU.py stores, MRT_GPU.py:207) or float64 (what MRT.py computes in)
     rows         : (y0, ny_local) when this object holds only a slab
     kernel       : 'auto' | 'generic' (one thread per cell) | 'vec' (16 B per access, MRT_GPU.py semantics) |
-                   'tb' (three to five steps per launch through LDS; what 'auto' picks when it applies)
+                   'tb' (three to five steps per launch through LDS; what 'auto' picks when it applies) |
+                   'push' (the reference's two-launch push scheme, for A/B only)
     layout       : device arrays 'planes' [k][y][x], 'rows' [y][k][x], 'auto' (= rows)
     arith        : 'strict' (default; the reference's operation order, bit-identical to the CPU restatement the tests check against) or 'fast' (MRT operator
                    in factored form, about half the arithmetic, agrees to rounding)

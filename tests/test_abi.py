@@ -51,7 +51,7 @@ def test_params_struct_layout():
 def test_enums_match_header():
     src = open(os.path.join(ROOT, "include", "lbm.h")).read()
     for name in ("LBM_F32", "LBM_F64", "LBM_SRT", "LBM_TRT", "LBM_MRT", "LBM_SEM_MRT_PY", "LBM_SEM_MRT_GPU",
-                 "LBM_KERNEL_AUTO", "LBM_KERNEL_GENERIC", "LBM_KERNEL_VEC", "LBM_KERNEL_TB", "LBM_SIDE_LOW", "LBM_SIDE_HIGH",
+                 "LBM_KERNEL_AUTO", "LBM_KERNEL_GENERIC", "LBM_KERNEL_VEC", "LBM_KERNEL_TB", "LBM_KERNEL_PUSH", "LBM_SIDE_LOW", "LBM_SIDE_HIGH",
                  "LBM_LAYOUT_AUTO", "LBM_LAYOUT_PLANES", "LBM_LAYOUT_ROWS", "LBM_ARITH_STRICT", "LBM_ARITH_FAST"):
         m = re.search(name + r"\s*=\s*(-?\d+)", src)
         assert m and int(m.group(1)) == getattr(_lib, name), name

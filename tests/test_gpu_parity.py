@@ -626,6 +626,32 @@ def test_fast_arithmetic_config_c1_centrelines():
         assert np.abs(fb[i] - ob.fin).max() / np.abs(ob.fin).max() < 1e-9
 
 
+@pytest.mark.parametrize("sem", ["mrt_gpu", "mrt_py"])
+@pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_push_scheme_equals_pull_kernels_and_oracle(sem, coll, dtype):
+    """kernel='push' is the reference's own two-launch scheme (collide-and-push into a persistent array, then wall
+    rules + copy: funRT + funBC); it must give the same bits as the fused pull kernels and the oracle, for odd and even step
+    counts, after an upload, and in the lagged u / rho."""
+    for nx, ny in ((40, 24), (132, 99), (17, 33)):
+        o = CavityOracleC(nx, ny, 400.0, semantics=sem, collision=coll, dtype=dtype)
+        with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=dtype, kernel="push") as p, \
+                CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=dtype) as q:
+            assert np.array_equal(p.get_fields(want_fin=True)[2], o.fin)
+            for n in (1, 2, 3, 40):
+                o.step(n); p.step(n); q.step(n)
+                same(p, o, f"push {sem} {coll} {nx}x{ny} after {o.nsteps}")
+                assert all(np.array_equal(a, b) for a, b in zip(p.get_fields(want_fin=True), q.get_fields(want_fin=True)))
+            _, _, fin = p.get_fields(want_fin=True)
+            p.set_state(fin); o.set_state(fin)
+            o.step(7); p.step(7)
+            same(p, o, "push after set_state")
+    with pytest.raises(RuntimeError, match="PUSH"):
+        CavitySolver(64, 64, 100.0, kernel="push", turb=1)
+    with pytest.raises(RuntimeError, match="PUSH"):
+        CavitySolver(64, 64, 100.0, kernel="push", rows=(0, 32))
+
+
 def test_fp32_tracks_fp64():
     with CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float64) as d, \
             CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float32) as f:
