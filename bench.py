@@ -218,6 +218,11 @@ def main():
                 other["one_step_per_launch"] = {"MLUPS": round(cells_total / ms1 / 1e3, 1), "ms_per_step": round(ms1, 5),
                                                 "algorithmic_GBps": round(alg_bytes_step / ms1 / 1e6, 1),
                                                 "frac_of_peak": round(alg_bytes_step / ms1 / 1e6 / HBM_PEAK_GBPS, 4)}
+                # the reference's own structure on this device: collide-and-push + wall-rule / copy kernel, two launches per step
+                with CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev, kernel="push") as s0:
+                    s0.step(10); s0.sync()
+                    ms0 = s0.time_steps(40) / 40
+                other["reference_scheme_push"] = {"MLUPS": round(cells_total / ms0 / 1e3, 1), "ms_per_step": round(ms0, 5)}
                 if a.arith == "fast":     # the same workload in the reference's exact operation order (bit-identical to the oracle)
                     with CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev, kernel=a.kernel, arith="strict") as s2:
                         s2.step(40); s2.sync()
