@@ -652,6 +652,29 @@ def test_push_scheme_equals_pull_kernels_and_oracle(sem, coll, dtype):
         CavitySolver(64, 64, 100.0, kernel="push", rows=(0, 32))
 
 
+@pytest.mark.parametrize("n,dtype,arith,steps", [(1024, np.float32, "fast", 20003), (1024, np.float64, "strict", 10001),
+                                                 (160, np.float32, "strict", 40005)])
+def test_long_run_multi_step_equals_one_step_kernel(n, dtype, arith, steps):
+    """Soak: tens of thousands of steps in irregular call lengths through the multi-step path (tile + fused frame workgroups,
+    LDS windows) against ONE call of the one-step-per-launch kernel: the same bits, run to run and path to path.
+    (`profiles/r01_logs/soak.log`: the same at 4096^2 and up to 300 000 steps.)"""
+    def run(kernel, chunks):
+        with CavitySolver(n, n, 1000.0, RT="MRT", dtype=dtype, arith=arith, kernel=kernel) as s:
+            for c in chunks:
+                s.step(c)
+            assert s.steps_done == steps
+            return s.get_fields(want_fin=True)
+    per = steps // 7
+    chunks = [per + (i % 3) for i in range(7)]
+    chunks[-1] += steps - sum(chunks)
+    a = run("auto", chunks)
+    b = run("auto", chunks)
+    c = run("vec", [steps])
+    assert np.isfinite(a[2]).all()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)), "run to run"
+    assert all(np.array_equal(x, y) for x, y in zip(a, c)), "multi-step path vs one step per launch"
+
+
 def test_fp32_tracks_fp64():
     with CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float64) as d, \
             CavitySolver(256, 256, 1000.0, RT="MRT", dtype=np.float32) as f:
