@@ -7,13 +7,15 @@
 
 One "step" = one fused pull-stream + collide pass over the whole lattice (all slabs).
 Workload (default): BASELINE.json configs[2] / north_star target -- 4096 x 4096 D2Q9 MRT cavity,
-Re = 1000, fp32, MRT_GPU.py semantics; for N > 1 every rank holds a 4096 x 4096 y-slab of a
-4096 x (4096 N) lattice (weak scaling) and exchanges a one-row halo with its neighbours by
-RCCL send/recv inside lbm_step().  Synthetic input: the reference's own initial state
-(equilibrium at rho = 1 with the moving lid, MRT_GPU.py:262-267), built on the device.
+Re = 1000, fp32, MRT_GPU.py semantics; for N > 1 that SAME lattice is cut into N y-slabs, one per rank
+(strong scaling, north_star: "4096^2 ... at 1/2/4/8 MI355X"), which exchange halos with their neighbours by
+RCCL send/recv inside lbm_step().  --config c4 (8192^2 fp64, Re 3200) is cut the same way; --config c5 is the
+weak series of configs[4]: every rank holds 16384 x 2048 of a 16384 x (2048 N) lattice, with omega fixed
+from the 8-GPU height 16384 (MRT_GPU.py:63 uses the global ysize).  Synthetic input: the reference's own initial
+state (equilibrium at rho = 1 with the moving lid, MRT_GPU.py:262-267), built on the device.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (algorithmic bytes
-per launch / HIP-event kernel time, against 8 TB/s) and `cpu_baseline` (the C oracle timed on
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (the binding physical limit of the
+dominant kernel, frac <= 1, formulas in DESIGN.md section 6) and `cpu_baseline` (the C oracle timed on
 this host's cores on a bounded sample of the same workload).
 """
 import argparse
@@ -29,14 +31,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+SIMDS = 256 * 4          # CUs x SIMDs
+CLOCK_PEAK_GHZ = 2.4     # max shader clock (same guide); the chip holds ~2.0-2.2 GHz under these kernels
+
 CONFIGS = {
     # name: (nx, ny_per_gpu, Re, dtype, RT, semantics, label)
     "c3": (4096, 4096, 1000.0, "float32", "MRT", "mrt_gpu", "BASELINE configs[2]: 4096x4096 D2Q9 MRT cavity Re=1000 fp32"),
     "c2": (1024, 1024, 1000.0, "float64", "MRT", "mrt_gpu", "BASELINE configs[1]: 1024x1024 D2Q9 MRT cavity Re=1000 fp64"),
     "c3f64": (4096, 4096, 1000.0, "float64", "MRT", "mrt_gpu", "4096x4096 D2Q9 MRT cavity Re=1000 fp64"),
-    "c4": (8192, 8192, 3200.0, "float64", "MRT", "mrt_gpu", "BASELINE configs[3] size: 8192x8192 D2Q9 MRT cavity Re=3200 fp64"),
-    "c5": (16384, 2048, 5000.0, "float32", "MRT", "mrt_gpu", "BASELINE configs[4]: 16384 wide, 2048 rows per GPU, Re=5000 fp32"),
+    "c4": (8192, 8192, 3200.0, "float64", "MRT", "mrt_gpu", "BASELINE configs[3]: 8192x8192 D2Q9 MRT cavity Re=3200 fp64"),
+    "c5": (16384, 2048, 5000.0, "float32", "MRT", "mrt_gpu", "BASELINE configs[4]: 16384 wide, 2048 rows per GPU, Re=5000 fp32, omega of the 16384-row lattice"),
 }
+DEFAULT_SCALING = {"c2": "strong", "c3": "strong", "c3f64": "strong", "c4": "strong", "c5": "weak"}   # as BASELINE.json words them
+OMEGA_HEIGHT = {"c5": 16384}    # the weak series keeps the relaxation rates of the 8-GPU lattice
 
 
 def host_cores():
@@ -113,6 +120,50 @@ def slab_of(config, scaling, world, rank):
     return ny_gpu, partition_rows(ny_gpu, world)[rank]
 
 
+def make_solver(config, scaling, world, rank, dev, kernel, arith, tuning=None):
+    """The CavitySolver of rank `rank` for a BASELINE configuration (whole lattice when world == 1)."""
+    from latticeboltzmannsimulations_amd import CavitySolver, relaxation
+    from latticeboltzmannsimulations_amd.slab import partition_rows
+    nx, ny_gpu, Re, dtype, RT, sem, _ = CONFIGS[config]
+    NY, rows = slab_of(config, scaling, world, rank)
+    mr = min(n for _, n in partition_rows(NY, world)) if world > 1 else None
+    s = CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev, rows=rows if world > 1 else None,
+                     kernel=kernel, arith=arith, min_rows=mr, tuning=tuning)
+    if config in OMEGA_HEIGHT:      # relaxation rates of the full-size lattice of the series, whatever this run's height
+        s.relax = relaxation(Re, OMEGA_HEIGHT[config], s.uLB, 1.2, 1.2)
+        s.set_relaxation(0, **s.relax)
+    return s, NY, rows
+
+
+def unit_plan(solver, steps):
+    """The launch units lbm_step(steps) will run from the solver's current (not just uploaded) state: [S1, S2, ...]."""
+    out, left = [], steps
+    while left > 0:
+        S = solver.next_unit(left)
+        out.append(S)
+        left -= S
+    return out
+
+
+def timed_rate(config, dev, kernel, arith, steps, warm):
+    """MLUPS and ms per step of a whole BASELINE configuration on one GPU, HIP events around `steps` steps (best of two)."""
+    s, NY, _ = make_solver(config, "strong", 1, 0, dev, kernel, arith)
+    try:
+        s.step(warm); s.sync()
+        ms = min(s.time_steps(steps) for _ in range(2)) / steps
+        return {"MLUPS": round(CONFIGS[config][0] * NY / ms / 1e3, 1), "ms_per_step": round(ms, 5), "steps": steps,
+                "steps_per_launch": s.next_unit(1000)}
+    finally:
+        s.close()
+
+
+def load_static(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-table", action="store_true", help="time the CPU restatements only (SURVEY 8d table) and exit")
@@ -125,13 +176,15 @@ def main():
                     help="fast: MRT operator in factored form with fused multiply-adds (agrees with the oracle to rounding, "
                          "tests/test_gpu_parity.py::test_fast_arithmetic_*); strict: the reference's operation order "
                          "(bit-identical to the oracle), also measured and reported under other.strict_arith")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="auto: as BASELINE.json words the configuration (c3 / c4: strong -- one lattice cut into N slabs; c5: weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short side measurements reported under 'other'")
     a = ap.parse_args()
     if a.cpu_table:
         cpu_table()
         return
+    scaling = DEFAULT_SCALING[a.config] if a.scaling == "auto" else a.scaling
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,7 +197,6 @@ def main():
 
     import torch                      # plumbing: process group, barrier, device sync
     import torch.distributed as dist
-    from latticeboltzmannsimulations_amd import CavitySolver
     from latticeboltzmannsimulations_amd.slab import attach_rccl
 
     if not torch.cuda.is_available():
@@ -159,9 +211,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     nx, ny_gpu, Re, dtype, RT, sem, label = CONFIGS[a.config]
-    NY, rows = slab_of(a.config, a.scaling, world, rank)
-    solver = CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev,
-                          rows=rows if world > 1 else None, kernel=a.kernel, arith=a.arith)
+    solver, NY, rows = make_solver(a.config, scaling, world, rank, dev, a.kernel, a.arith)
     if world > 1:
         attach_rccl(solver, rank, world)
 
@@ -177,8 +227,9 @@ def main():
     wake_gbps = solver.copy_bandwidth(1 << 30, 100)
     solver.step(a.warmup)
     fence()
+    units = unit_plan(solver, a.steps)        # the launches the K timed steps consist of
     t0 = time.perf_counter()
-    ev_ms = solver.time_steps(a.steps)      # HIP events on the compute stream around the K launches
+    ev_ms = solver.time_steps(a.steps)      # HIP events on the compute stream around the K steps
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -190,45 +241,95 @@ def main():
     cells_rank = nx * rows[1]
     es = np.dtype(dtype).itemsize
     mlups = cells_total * a.steps / dt / 1e6
-    # SURVEY 8(d): algorithmic bytes per lattice update = read 9 + write 9 populations = 18 * sizeof(real).
-    # The dominant kernel (k_stepS_deep, S = 5 time steps per launch for fp32 fast, 4 strict, 3 for fp64) performs S updates of every interior
-    # cell per launch; the K timed steps are about K/S such launches + 1..S single-step launches, bracketed by HIP events on
-    # the compute stream.
-    alg_bytes_step = cells_rank * 2 * 9 * es
     step_ms = ev_ms / a.steps
-    achieved = alg_bytes_step / (step_ms * 1e-3) / 1e9
+    # SURVEY 8(d): algorithmic bytes per lattice update = read 9 + write 9 populations = 18 * sizeof(real).
+    alg_bytes_step = cells_rank * 2 * 9 * es
+    algorithmic_GBps = alg_bytes_step / (step_ms * 1e-3) / 1e9
 
     out = None
     if rank == 0:
+        # ---- roofline of the dominant kernel: a launch unit of S steps = ONE launch of k_stepS_deep (tiles + wall frame) ------
+        # Its own minimum HBM traffic is one read and one write of the lattice per LAUNCH (2 * 9 * sizeof(real) * cells), whatever
+        # S: that is the byte count of the HBM line below, so frac <= 1 by construction; `algorithmic_GBps` keeps SURVEY 8(d)'s
+        # per-update figure (which a temporally blocked kernel can exceed).  The launch duration is the HIP-event time of the
+        # timed region divided by its launch units (with the default plan every unit is the same kernel at the same S; single
+        # steps, if the step count leaves a remainder, are counted as units of their own).
+        S_dom = max(units) if units else 1
+        n_dom = sum(1 for u in units if u == S_dom)
+        pure = bool(units) and all(u == S_dom for u in units)
+        launch_ms = ev_ms / len(units) if units else float("nan")
+        min_bytes_launch = cells_rank * 2 * 9 * es
+        hbm_achieved = min_bytes_launch / (launch_ms * 1e-3) / 1e9
+        kname = {"auto": "k_stepS_deep", "tb": "k_stepS_deep", "vec": "k_step_vec", "generic": "k_step_generic", "push": "k_push_collide+k_push_bc"}.get(a.kernel, a.kernel)
+        key = f"{a.config}:{world}:{a.kernel}:{a.arith}"
+        tr = load_static("traffic.json").get(key, {})
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get(f"{a.config}:{world}:{a.kernel}:{a.arith}", {}).get("hbm_bytes_per_step")
-            except Exception:
-                traffic = None
+        if tr and tr.get("steps_per_launch", S_dom) == S_dom:       # PMC bytes of this kernel at this S, from the committed profile
+            traffic = tr.get("hbm_bytes_per_launch")
+        vm = load_static("valu_mix.json").get(f"{kname}:{dtype}:{RT}:{a.arith}:S{S_dom}", {})
+        valu = None
+        if vm and S_dom > 1:
+            # VALU issue line: issue cycles of one workgroup's instruction stream (disassembly x measured issue cost per
+            # instruction class, tools/valu_mix.py + tools/valu_issue.hip) x workgroups per launch, over the cycles the 1024
+            # SIMDs offer during the launch at the 2.4 GHz peak clock
+            wgs = tr.get("workgroups_per_launch") or vm.get("workgroups_4096")
+            if wgs:
+                cyc = vm["issue_cycles_per_workgroup"] * wgs
+                valu = {"issue_cycles_per_launch": cyc, "frac": round(cyc / (launch_ms * 1e-3 * CLOCK_PEAK_GHZ * 1e9 * SIMDS), 4),
+                        "source": vm.get("source")}
+        roof = {"bound": "hbm", "achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(hbm_achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "kernel": kname, "steps_per_launch": S_dom, "launches_timed": len(units), "launch_ms": round(launch_ms, 5),
+                "bytes_per_launch": min_bytes_launch,
+                "traffic_static": True if traffic is not None else None,
+                "traffic_source": tr.get("source") if traffic is not None else None,
+                "traffic_GBps": None if traffic is None else round(traffic / (launch_ms * 1e-3) / 1e9, 1),
+                "traffic_frac_of_peak": None if traffic is None else round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "valu_issue": valu,
+                "algorithmic_GBps": round(algorithmic_GBps, 1), "algorithmic_bytes_per_step": alg_bytes_step,
+                "event_ms_per_step": round(step_ms, 5), "units": units if len(units) <= 12 else units[:6] + ["..."] + units[-3:],
+                "note": "achieved = (one read + one write of the lattice = the kernel's minimum HBM bytes per launch) / launch duration "
+                        "(HIP events over the timed region / launches); one launch advances steps_per_launch time steps through LDS, so "
+                        "SURVEY 8(d)'s per-update figure is reported separately as algorithmic_GBps = 72 or 144 B x updates / time and is "
+                        "not a bound; traffic = PMC FETCH_SIZE x 2 + WRITE_SIZE of the same kernel from the committed rocprofv3 profile "
+                        "(static, not measured in this run)" + ("" if pure else "; the timed region mixes launch units of different length")}
+        if valu and valu["frac"] > roof["frac"] and (roof["traffic_frac_of_peak"] or 0) < valu["frac"]:
+            roof["binding"] = "valu_issue"          # (informational: the larger fraction is the nearer limit)
+        else:
+            roof["binding"] = "hbm"
         other = {}
         if not a.no_extra and world == 1:
             try:
                 other["device_copy_GBps"] = round(wake_gbps, 1)
                 # the same workload advanced ONE step per launch (k_step_vec): the HBM-streaming reference point
-                with CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev, kernel="vec") as s1:
+                s1, _, _ = make_solver(a.config, scaling, 1, 0, dev, "vec", "strict")
+                with s1:
                     s1.step(10); s1.sync()
                     ms1 = s1.time_steps(50) / 50
                 other["one_step_per_launch"] = {"MLUPS": round(cells_total / ms1 / 1e3, 1), "ms_per_step": round(ms1, 5),
-                                                "algorithmic_GBps": round(alg_bytes_step / ms1 / 1e6, 1),
+                                                "hbm_GBps": round(alg_bytes_step / ms1 / 1e6, 1),
                                                 "frac_of_peak": round(alg_bytes_step / ms1 / 1e6 / HBM_PEAK_GBPS, 4)}
                 # the reference's own structure on this device: collide-and-push + wall-rule / copy kernel, two launches per step
-                with CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev, kernel="push") as s0:
+                s0, _, _ = make_solver(a.config, scaling, 1, 0, dev, "push", "strict")
+                with s0:
                     s0.step(10); s0.sync()
                     ms0 = s0.time_steps(40) / 40
                 other["reference_scheme_push"] = {"MLUPS": round(cells_total / ms0 / 1e3, 1), "ms_per_step": round(ms0, 5)}
-                if a.arith == "fast":     # the same workload in the reference's exact operation order (bit-identical to the oracle)
-                    with CavitySolver(nx, NY, Re, RT=RT, semantics=sem, dtype=np.dtype(dtype), device=dev, kernel=a.kernel, arith="strict") as s2:
-                        s2.step(40); s2.sync()
-                        ms2 = min(s2.time_steps(200) for _ in range(2)) / 200
-                    other["strict_arith"] = {"MLUPS": round(cells_total / ms2 / 1e3, 1), "ms_per_step": round(ms2, 5),
-                                             "algorithmic_GBps": round(alg_bytes_step / ms2 / 1e6, 1)}
+                if a.arith == "fast":     # the same workload in the reference's exact operation order (bit-identical to the oracle),
+                    s2, _, _ = make_solver(a.config, scaling, 1, 0, dev, a.kernel, "strict")    # same step count as the headline
+                    with s2:
+                        s2.step(max(a.warmup, 40)); s2.sync()
+                        ms2 = min(s2.time_steps(a.steps) for _ in range(2)) / a.steps
+                        other["strict_arith"] = {"MLUPS": round(cells_total / ms2 / 1e3, 1), "ms_per_step": round(ms2, 5),
+                                                 "steps": a.steps, "steps_per_launch": s2.next_unit(1000),
+                                                 "note": "reference operation order, bit-identical to the oracle"}
+                # the other BASELINE configurations on this one GPU (whole lattice; c5: the per-GPU slab of the weak series)
+                for cfg, n in (("c2", 200), ("c3f64", 100), ("c4", 50), ("c5", 100)):
+                    if cfg == a.config:
+                        continue
+                    other[cfg] = {"workload": CONFIGS[cfg][6]}
+                    for ar in ("fast", "strict"):
+                        other[cfg][ar] = timed_rate(cfg, dev, "auto", ar, n, 20)
                 # the headline input is the prescribed rest state; the same measurement on populations with +-1e-3
                 # relative noise (numpy default_rng(0), fp32 noise field), same wake-up, warm-up and step count: the rate does
                 # not depend on the data (profiles/r01_logs/clock_probe.log: 61.2 vs 61.4 us per step over 30 000 steps, the
@@ -240,7 +341,7 @@ def main():
                 solver.set_state(fin)
                 del fin
                 solver.copy_bandwidth(1 << 30, 100)     # the device idled while the host built the noise: wake it up again
-                solver.step(a.warmup); solver.sync()
+                solver.step(max(a.warmup, 6)); solver.sync()
                 msn = solver.time_steps(a.steps) / a.steps
                 other["noisy_state"] = {"MLUPS": round(cells_total / msn / 1e3, 1), "ms_per_step": round(msn, 5)}
             except Exception as e:      # measurement nicety only
@@ -248,22 +349,16 @@ def main():
         out = {
             "metric": "MLUPS (million lattice updates/sec) D2Q9 MRT cavity",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": a.scaling,
+            "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32" if dtype == "float32" else "f64", "data": "synthetic",
             "config": {"workload": label + (f"; {world} y-slabs of {nx}x{rows[1]}, lattice {nx}x{NY}" if world > 1 else ""),
                        "lattice": [nx, NY], "Re": Re, "collision": RT, "semantics": sem, "kernel": a.kernel,
                        "arith": a.arith + (" (factored MRT operator + fused multiply-adds; same operator, agrees with the strict path "
-                                           "to rounding)" if a.arith == "fast" else " (reference operation order, bit-identical to the oracle)"),
-                       "halo": "rccl send/recv inside lbm_step, overlapped" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         # the bytes really moved (PMC, per step) over the same time: the physical HBM rate of the launch mix
-                         "traffic_GBps": None if traffic is None else round(traffic / (step_ms * 1e-3) / 1e9, 1),
-                         "traffic_frac_of_peak": None if traffic is None else round(traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "event_ms_per_step": round(step_ms, 5), "algorithmic_bytes_per_step": alg_bytes_step,
-                         "note": "achieved = algorithmic bytes (18 words per cell update) / HIP-event time; with several time steps "
-                                 "fused per launch through LDS the HBM bytes actually moved (traffic, per step) are below the "
-                                 "algorithmic bytes, so achieved can exceed the physical peak"},
+                                           "to rounding, not bit for bit; the reference-order path is other.strict_arith)" if a.arith == "fast"
+                                           else " (reference operation order, bit-identical to the oracle)"),
+                       "halo": (f"rccl send/recv inside lbm_step: {S_dom} complete rows per side before each {S_dom}-step launch, overlapped"
+                                if world > 1 else "none")},
+            "roofline": roof,
         }
         if other:
             out["other"] = other

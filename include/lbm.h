@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 2
+#define LBM_ABI_VERSION 3
 
 typedef enum lbm_status {
     LBM_OK = 0,
@@ -46,6 +46,17 @@ enum { LBM_KERNEL_AUTO = 0,      /* fastest applicable: TB (lattices from 64 x 6
 enum { LBM_LAYOUT_AUTO = 0, LBM_LAYOUT_PLANES = 1, LBM_LAYOUT_ROWS = 2 }; /* device arrays: [k][y][x] or [y][k][x] */
 enum { LBM_ARITH_STRICT = 0, LBM_ARITH_FAST = 1 };
 enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour towards smaller / larger y */
+/* lbm_params.flags: A/B switches of the launch plan (all off = the measured defaults); results never depend on them */
+enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange after every frame pass of a multi-step launch instead
+                                            of ONE exchange of S complete rows per launch */
+       LBM_FLAG_FRAME_UNFUSED = 2,       /* one launch per frame pass instead of all passes inside the tile launch */
+       LBM_FLAG_FRAME_FUSED_BATCH = 4,   /* batches too run the frame passes inside the tile launch */
+       LBM_FLAG_NO_FRAME_LDS = 8,        /* intermediate frame passes through scratch lattices instead of LDS windows */
+       LBM_FLAG_NT_ON = 16,              /* non-temporal loads / stores on (default: lattices above 192 MiB) ... */
+       LBM_FLAG_NT_OFF = 32,             /* ... or off */
+       LBM_FLAG_COMM_PRIORITY_OFF = 64,  /* communication stream at the compute stream's priority */
+       LBM_FLAG_EAGER_LAG = 128 };       /* every lbm_step() call ends with a single step (so that the lattice of the step before
+                                            the last exists) instead of recomputing it when lbm_get_fields asks for u / rho */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
  * reference bakes them into the CUDA source by '%'-formatting (MRT_GPU.py:422,531,662) and
@@ -74,6 +85,12 @@ typedef struct lbm_params {
                             instructions (fp32: 1 ulp; fp64: refined by Newton steps).
                             Results agree with the strict form to rounding, not bit for bit.  MRT_GPU semantics only
                             (with LBM_SEM_MRT_PY the strict form is used). */
+    int32_t ny_local_min; /* slabs: the smallest ny_local of ALL ranks (0: = ny_local).  The launch plan (steps per launch, frame
+                            width, deep halo) is derived from it, so that every rank of a decomposition runs the same exchange
+                            protocol whatever its own share of the rows; lbm_comm_init() cross-checks the plan with both neighbours. */
+    int32_t tb_steps;    /* 0: measured default.  2 .. 5: time steps per launch of the multi-step path (A/B, tests) */
+    int32_t frame_seg;   /* 0: default by lattice size.  >= 8: cells of the wall frame per workgroup of the fused frame passes */
+    int32_t flags;       /* LBM_FLAG_* bits, 0 = defaults */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */
     double omega;        /* = omegap = omega_nu, MRT_GPU.py:65 */
     double omegam;       /* TRT, MRT_GPU.py:80 */
@@ -115,8 +132,10 @@ int lbm_set_relaxation(lbm_ctx* c, int index, double omega, double omegam, doubl
 /* --- time loop --------------------------------------------------------------------- */
 /* replaces: funRT(...); funBC(...) launched from the Python loop (MRT_GPU.py:707-732).
  * Enqueues nsteps fused steps and returns without waiting (errors surface at the next
- * synchronising call, like pycuda LaunchError).  With an RCCL communicator attached the
- * one-row halo exchange with the slab neighbours is part of every step. */
+ * synchronising call, like pycuda LaunchError).  Large lattices advance several steps per launch
+ * (lbm_next_unit).  With an RCCL communicator attached the halo exchange with the slab neighbours is
+ * part of every launch unit.  A slab (y0 > 0 or y0 + ny_local < ny) WITHOUT a communicator is refused
+ * (LBM_ERR_STATE): its ghost rows would never be filled -- use the externally driven calls below. */
 int lbm_step(lbm_ctx* c, int nsteps);
 /* replaces: the implicit synchronisation of cuda.memcpy_dtoh (MRT_GPU.py:755) */
 int lbm_sync(lbm_ctx* c);
@@ -125,6 +144,10 @@ int lbm_sync(lbm_ctx* c);
 int lbm_time_steps(lbm_ctx* c, int nsteps, double* ms);
 /* iterations performed since the last lbm_init_equilibrium / lbm_set_state */
 long long lbm_steps_done(const lbm_ctx* c);
+/* The launch plan of lbm_step(): number of time steps the next launch unit advances when `steps_left` remain
+ * (1 = a single step; S > 1 = one multi-step launch of S steps).  Depends only on the parameters, ny_local_min and
+ * whether the lattice has just been uploaded -- the same on every rank of a decomposition. */
+int lbm_next_unit(const lbm_ctx* c, int steps_left);
 
 /* --- state out --------------------------------------------------------------------- */
 /* replaces: cuda.memcpy_dtoh(fin, ftemp_g); memcpy_dtoh(rho, rho_g); memcpy_dtoh(u, u_g)
@@ -133,8 +156,20 @@ long long lbm_steps_done(const lbm_ctx* c);
  * reference: u_g/rho_g are written inside funRT before collide/stream); fin_host
  * [9][nx][ny] receives the current populations (post stream + wall rules).  Any pointer
  * may be NULL.  Whole-lattice arrays; only this context's rows are written.
- * With batch = B > 1: u_host[B][2][nx][ny], rho_host[B][nx][ny], fin_host[B][9][nx][ny]. */
+ * With batch = B > 1: u_host[B][2][nx][ny], rho_host[B][nx][ny], fin_host[B][9][nx][ny].
+ * (When the last launch unit advanced S > 1 steps, the lattice of the step before the last is recomputed here from the
+ * unit's source lattice, S - 1 steps, bit-identically; nothing of that is on the path of lbm_step.) */
 int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int host_dtype);
+/* replaces: the download of u_g + np.mean(u) of the convergence test (MRT_GPU.py:883, MRT_GPU_datagen.py:862-871) by a
+ * reduction on the device: mean_out[b] = mean over both components and all cells of this context's rows of the u that
+ * lbm_get_fields would return, accumulated in double in a fixed order (deterministic); one double per lattice of the batch
+ * crosses PCIe.  (The reference's criterion is defined on NumPy's float32 pairwise mean of the downloaded field; the two
+ * means differ in the last bits of a float -- the host form stays available through lbm_get_fields.) */
+int lbm_mean_u(lbm_ctx* c, double* mean_out);
+/* replaces: taus_g (MRT_GPU.py:387; never downloaded by the reference, its dashboard prints mean(tauS), MRT_GPU.py:862-866).
+ * tau_host[nx][ny] receives the relaxation time tau + tau_turbulent of the LAST iteration; with turb = 0 the constant
+ * 1 / omega.  With batch = B > 1: tau_host[B][nx][ny]. */
+int lbm_get_tau(lbm_ctx* c, void* tau_host, int host_dtype);
 
 /* --- slab decomposition, externally driven exchange ---------------------------------- */
 /* No reference counterpart (the reference is single-GPU, MRT_GPU.py:29).  A step of a slab
@@ -146,20 +181,34 @@ int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int
  * i.e. every step is followed by the exchange of the rows it wrote (lbm_get_fields needs
  * current ghost rows to return the populations of the slab's first and last row).
  * lbm_halo_elems() = elements of one packed halo (3 planes x nx).  buf may be device or
- * host memory. */
+ * host memory.
+ *
+ * Multi-step launch units between slabs (MRT_GPU semantics; what lbm_step runs when lbm_next_unit() > 1): before a unit of
+ * S steps every slab hands the S COMPLETE rows next to each interface to its neighbour --
+ *     lbm_halo_export_rows(side, S) -> transport -> lbm_halo_import_rows(side, S)      (lbm_halo_rows_elems(S) elements)
+ * -- then lbm_step_unit(S) advances the slab S steps with no further communication: the frame passes recompute a shrinking
+ * band of the neighbour's rows.  lbm_step_unit is exactly the launch sequence lbm_step uses between ranks (same kernels,
+ * streams and events), minus the RCCL calls; lbm_step = this protocol with the transport inside. */
 int lbm_halo_elems(const lbm_ctx* c);
 int lbm_halo_export(lbm_ctx* c, int side, void* buf);
 int lbm_halo_import(lbm_ctx* c, int side, const void* buf);
 int lbm_step_edges(lbm_ctx* c);
 int lbm_step_interior(lbm_ctx* c);
 int lbm_step_finish(lbm_ctx* c);
+long long lbm_halo_rows_elems(const lbm_ctx* c, int nrows);
+int lbm_halo_export_rows(lbm_ctx* c, int side, int nrows, void* buf);
+int lbm_halo_import_rows(lbm_ctx* c, int side, int nrows, const void* buf);
+int lbm_step_unit(lbm_ctx* c, int unit_steps);
 
 /* --- slab decomposition, RCCL exchange inside lbm_step -------------------------------- */
 /* uid_out: 128 bytes (ncclUniqueId) created on one rank and distributed by the caller
  * (e.g. torch.distributed broadcast).  After lbm_comm_init, lbm_step() exchanges halos with
  * rank-1 / rank+1 by ncclSend/ncclRecv on a second HIP stream, overlapped with the
- * interior rows: one row of three directions per single step; before a launch that advances S
- * steps, the S complete rows next to each interface in one message per side (MRT_GPU semantics). */
+ * interior rows: one row of three directions before a single step; before a launch that advances S
+ * steps, the S complete rows next to each interface in one message per side (MRT_GPU semantics).
+ * Rank r must hold the r-th slab from the lid (rank 0: y0 = 0, last rank: y0 + ny_local = ny).  lbm_comm_init compares
+ * the launch plan (steps per launch, frame width, deep halo, row pitch, planes) with both neighbours and fails with
+ * LBM_ERR_STATE if they differ (pass the same lbm_params.ny_local_min on every rank). */
 int lbm_comm_unique_id(void* uid_out128);
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128);
 /* Diagnostic for one-GPU machines: attaches a ONE-rank RCCL communicator and makes the slab its own

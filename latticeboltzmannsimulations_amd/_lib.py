@@ -23,7 +23,10 @@ LBM_KERNEL_AUTO, LBM_KERNEL_GENERIC, LBM_KERNEL_VEC, LBM_KERNEL_TB, LBM_KERNEL_P
 LBM_LAYOUT_AUTO, LBM_LAYOUT_PLANES, LBM_LAYOUT_ROWS = 0, 1, 2
 LBM_SIDE_LOW, LBM_SIDE_HIGH = 0, 1
 LBM_ARITH_STRICT, LBM_ARITH_FAST = 0, 1
-ABI_VERSION = 2        # = LBM_ABI_VERSION of include/lbm.h (tests/test_abi.py keeps them equal)
+# lbm_params.flags (A/B switches of the launch plan; results never depend on them)
+LBM_FLAG_NO_DEEP_HALO, LBM_FLAG_FRAME_UNFUSED, LBM_FLAG_FRAME_FUSED_BATCH, LBM_FLAG_NO_FRAME_LDS = 1, 2, 4, 8
+LBM_FLAG_NT_ON, LBM_FLAG_NT_OFF, LBM_FLAG_COMM_PRIORITY_OFF, LBM_FLAG_EAGER_LAG = 16, 32, 64, 128
+ABI_VERSION = 3        # = LBM_ABI_VERSION of include/lbm.h (tests/test_abi.py keeps them equal)
 
 
 class lbm_params(ctypes.Structure):
@@ -31,7 +34,8 @@ class lbm_params(ctypes.Structure):
                 ("y0", ctypes.c_int32), ("ny_local", ctypes.c_int32), ("dtype", ctypes.c_int32),
                 ("collision", ctypes.c_int32), ("semantics", ctypes.c_int32), ("kernel", ctypes.c_int32),
                 ("turb", ctypes.c_int32), ("device", ctypes.c_int32), ("layout", ctypes.c_int32),
-                ("batch", ctypes.c_int32), ("arith", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("arith", ctypes.c_int32), ("ny_local_min", ctypes.c_int32),
+                ("tb_steps", ctypes.c_int32), ("frame_seg", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("uLB", ctypes.c_double), ("omega", ctypes.c_double), ("omegam", ctypes.c_double),
                 ("omega_e", ctypes.c_double), ("omega_eps", ctypes.c_double), ("omega_q", ctypes.c_double)]
 
@@ -91,13 +95,20 @@ SIGNATURES = {
     "lbm_sync": (_i, [_vp]),
     "lbm_time_steps": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "lbm_steps_done": (ctypes.c_longlong, [_vp]),
+    "lbm_next_unit": (_i, [_vp, _i]),
     "lbm_get_fields": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "lbm_mean_u": (_i, [_vp, ctypes.POINTER(_d)]),
+    "lbm_get_tau": (_i, [_vp, _vp, _i]),
     "lbm_halo_elems": (_i, [_vp]),
     "lbm_halo_export": (_i, [_vp, _i, _vp]),
     "lbm_halo_import": (_i, [_vp, _i, _vp]),
     "lbm_step_edges": (_i, [_vp]),
     "lbm_step_interior": (_i, [_vp]),
     "lbm_step_finish": (_i, [_vp]),
+    "lbm_halo_rows_elems": (ctypes.c_longlong, [_vp, _i]),
+    "lbm_halo_export_rows": (_i, [_vp, _i, _i, _vp]),
+    "lbm_halo_import_rows": (_i, [_vp, _i, _i, _vp]),
+    "lbm_step_unit": (_i, [_vp, _i]),
     "lbm_comm_unique_id": (_i, [_vp]),
     "lbm_comm_init": (_i, [_vp, _i, _i, _vp]),
     "lbm_comm_loopback": (_i, [_vp]),

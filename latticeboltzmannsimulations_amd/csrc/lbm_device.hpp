@@ -262,12 +262,16 @@ __device__ __forceinline__ f32x2 real_abs(f32x2 x) { return f32x2{fabsf(x.x), fa
 
 // T: scalar real or f32x2; the result is the per-cell relaxation rate (a T, not a scalar)
 template <typename T, bool FAST = false>
-__device__ __forceinline__ T smagorinsky_omega(const T (&f)[Q], T qeq_prev, T rho_prev, typename ScalarOf<T>::type omega) {
+__device__ __forceinline__ T smagorinsky_tau(const T (&f)[Q], T qeq_prev, T rho_prev, typename ScalarOf<T>::type omega) {   // taus_g, MRT_GPU.py:385-387
     typedef typename ScalarOf<T>::type R;
     const R tau0 = (R)1.0 / omega;
     const T q = diag_flux<T>(f) - qeq_prev;
-    const T tau = (R)0.5 * (tau0 + sqrt_<FAST>(tau0 * tau0 + div_<FAST>(((R)(18 * 1.4142) * (R)0.025) * real_abs(q), rho_prev)));
-    return div_<FAST>(T((R)1.0), tau);
+    return (R)0.5 * (tau0 + sqrt_<FAST>(tau0 * tau0 + div_<FAST>(((R)(18 * 1.4142) * (R)0.025) * real_abs(q), rho_prev)));
+}
+template <typename T, bool FAST = false>
+__device__ __forceinline__ T smagorinsky_omega(const T (&f)[Q], T qeq_prev, T rho_prev, typename ScalarOf<T>::type omega) {
+    typedef typename ScalarOf<T>::type R;
+    return div_<FAST>(T((R)1.0), smagorinsky_tau<T, FAST>(f, qeq_prev, rho_prev, omega));
 }
 
 // a8: wall rules on the populations of ONE perimeter cell, given the equilibrium of the

@@ -28,32 +28,50 @@ __global__ __launch_bounds__(BLK) void k_copy16(const uint4* __restrict__ a, uin
     for (; i < n; i += stride) b[i] = a[i];
 }
 
+// out[z] = scale * (partial[z * nper + 0] + partial[z * nper + 1] + ...), added in index order by one thread per lattice
+__global__ __launch_bounds__(BLK) void k_reduce_final(const double* __restrict__ partial, int nper, int nlat, double scale, double* __restrict__ out) {
+    const int z = blockIdx.x * BLK + threadIdx.x;
+    if (z >= nlat) return;
+    double a = 0.0;
+    for (int i = 0; i < nper; ++i) a += partial[(size_t)z * nper + i];
+    out[z] = scale * a;
+}
+
 // ------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------
+constexpr int LAT_LAG = 6;    // lat[LAT_LAG]: the lattice of the step before the last, recomputed on demand (lazy one-step lag)
+constexpr int NLAT = 7;
+
 struct lbm_ctx {
     lbm_params p{};
     int es = 0;  // element size
     Geo geo{};
-    void* lat[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0], [1]: the two lattices; [2] ..: frame scratch of the multi-step
-    int raw[2] = {1, 1};
+    void* lat[NLAT] = {};       // [0], [1]: the two lattices; [2] .. [5]: frame scratch of the multi-step; [LAT_LAG]: see above
+    size_t lat_bytes = 0;
+    int raw[NLAT] = {1, 1, 0, 0, 0, 0, 0};
     int cur = 0;  // lat[cur] is the source of the next step
     long long nsteps = 0;
+    // One-step lag of u / rho: the fields of the last iteration are moments of the state it started from.
+    // After a single step that state is still in lat[cur ^ 1] (lag = 0).  After a launch unit of S steps lat[cur ^ 1] holds the
+    // state S steps back: lag = S - 1 steps are recomputed from it into lat[LAT_LAG] when lbm_get_fields / lbm_mean_u /
+    // lbm_get_tau ask (lag_valid: done already) -- bit-identical, and off the path of lbm_step.
+    int lag = 0;
+    bool lag_valid = false;
+    bool lazy_lag = true;       // (LBM_FLAG_EAGER_LAG: every lbm_step call ends with a single step instead)
     hipStream_t s_compute = nullptr, s_comm = nullptr;
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    double* red_dev = nullptr;  // lbm_mean_u: partial sums + results
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
-    bool halo_pending = false;  // an exchange into lat[cur] has been enqueued on s_comm
-    bool frame_lds = true;      // ... keeping the intermediate passes in LDS when their windows fit (LBM_FRAME_LDS=0: scratch lattices)
-    int frame_seg = 64;         // cells of the frame per workgroup of the fused frame passes (LBM_FRAME_SEG)
- bool frame_fused = true;    // all frame passes of a multi-step in one launch (LBM_FRAME_FUSED=0: one launch per pass)
-    int deep_rows = 0;          // ... and it was a deep one: this many complete rows per side (for the next multi-step)
-    bool deep_halo = false;     // multi-steps between slabs exchange once per launch (MRT_GPU semantics; LBM_DEEP_HALO=0 disables)
+    bool thin_valid = false;    // the one-row halo of lat[cur] has been exchanged (by the RCCL path, on s_comm)
+    bool frame_lds = true;      // ... keeping the intermediate passes in LDS when their windows fit (LBM_FLAG_NO_FRAME_LDS: scratch lattices)
+    int frame_seg = 64;         // cells of the frame per workgroup of the fused frame passes (lbm_params.frame_seg)
+    bool frame_fused = true;    // all frame passes of a multi-step in one launch (LBM_FLAG_FRAME_UNFUSED: one launch per pass)
+    bool deep_halo = false;     // multi-steps between slabs exchange once per launch (MRT_GPU semantics; LBM_FLAG_NO_DEEP_HALO disables)
     bool loopback = false;      // diagnostic: 1-rank communicator, the slab exchanges halos with itself
-    int loop_sides = 3;         // ... through these sides (bit LBM_SIDE_LOW / LBM_SIDE_HIGH; LBM_DEBUG_LOOPBACK_SIDES: tests of the
-                                // one-neighbour code paths of the first / last rank; the other side then reads its never-written ghost rows)
     bool use_vec = false;       // vector kernel (MRT_GPU.py semantics, nx multiple of the vector width)
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
@@ -182,15 +200,15 @@ void dispatch(const lbm_params& p, F&& f) {
     else by_coll(double{});
 }
 
-// One single step, lat[cur] -> lat[cur^1], on local rows row0 + i*stride, i in [0, nrows).
-int launch_rows(lbm_ctx* c, int row0, int stride, int nrows, hipStream_t s) {
+// One single step, lat[from] -> lat[to], on local rows row0 + i*stride, i in [0, nrows).
+int launch_rows(lbm_ctx* c, int from, int to, int row0, int stride, int nrows, hipStream_t s) {
     if (nrows <= 0) return LBM_OK;
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
-        const R* src = (const R*)c->lat[c->cur];
-        R* dst = (R*)c->lat[c->cur ^ 1];
-        const int raw = c->raw[c->cur];
+        const R* src = (const R*)c->lat[from];
+        R* dst = (R*)c->lat[to];
+        const int raw = c->raw[from];
         if (VT::SEM == SEM_GPU && c->use_vec) {
             constexpr int V = 16 / (int)sizeof(R);
             const int nxb = (c->geo.nx / V + BLK - 1) / BLK, nblocks = nxb * nrows;
@@ -288,10 +306,14 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
     return LBM_OK;
 }
 
-void finish_step(lbm_ctx* c) {
+// bookkeeping after a launch unit of S steps lat[cur] -> lat[cur ^ 1]
+void finish_unit(lbm_ctx* c, int S) {
     c->cur ^= 1;
     c->raw[c->cur] = c->push ? 1 : 0;   // (push scheme: the lattices hold plain populations, nothing to stream at read time)
-    c->nsteps += 1;
+    c->nsteps += S;
+    c->lag = S - 1;
+    c->lag_valid = false;
+    c->thin_valid = false;
 }
 
 // x-range [lo, hi] of plane k that a slab neighbour actually pulls from a halo row
@@ -335,18 +357,28 @@ int sync_all(lbm_ctx* c) {
     return LBM_OK;
 }
 
-// Does the slab have a neighbour through this side?  Between ranks: rank - 1 / rank + 1.  In loopback mode (one GPU, the slab
-// is its own neighbour) every side that is not a global wall wraps around.
+// Is there a slab beyond this side?  Geometry decides (the slab does not touch the lid / the bottom wall there): the frame
+// passes of a multi-step extend into the ghost rows of such a side whatever moves the rows -- RCCL between ranks
+// (lbm_comm_init checks that rank r holds the r-th slab), the loopback diagnostic, or the caller (lbm_halo_*_rows).
 bool has_neighbour(const lbm_ctx* c, int side) {
-    if (c->loopback) return (c->loop_sides >> side) & 1;
-    if (c->nranks <= 1) return false;
-    return side == LBM_SIDE_LOW ? c->rank > 0 : c->rank < c->nranks - 1;
+    return side == LBM_SIDE_LOW ? c->geo.y0 > 0 : c->geo.y0 + c->geo.ny < c->geo.NY;
 }
+bool is_slab(const lbm_ctx* c) { return has_neighbour(c, LBM_SIDE_LOW) || has_neighbour(c, LBM_SIDE_HIGH); }
+// the library itself moves the halos (RCCL between ranks, or the one-GPU loopback)
+bool own_transport(const lbm_ctx* c) { return c->comm != nullptr && (c->nranks > 1 || c->loopback); }
 
-// RCCL exchange of the rows of lat[which] with both neighbours, on s_comm
+#ifdef LBM_DEBUG
+bool debug_skip_exchange() {   // timing diagnostic of debug builds only: results between slabs are wrong
+    static const bool skip = std::getenv("LBM_DEBUG_SKIP_EXCHANGE") != nullptr;
+    return skip;
+}
+#else
+constexpr bool debug_skip_exchange() { return false; }
+#endif
+
+// RCCL exchange of the one-row halo of lat[which] with both neighbours, on s_comm
 int enqueue_exchange(lbm_ctx* c, int which) {
-    static const bool skip = std::getenv("LBM_DEBUG_SKIP_EXCHANGE") != nullptr;   // timing diagnostic only: wrong results
-    if (skip) return LBM_OK;
+    if (debug_skip_exchange()) return LBM_OK;
     const ncclDataType_t dt = c->p.dtype == LBM_F32 ? ncclFloat : ncclDouble;
     const int ny = c->geo.ny;
     NCCL_TRY(c, rccl().GroupStart());
@@ -382,107 +414,117 @@ int enqueue_exchange(lbm_ctx* c, int which) {
 // is what the per-pass scheme cannot hide: 739 KB once instead of 5 x 48 KB.  MRT_GPU semantics only: there a
 // side-wall cell overwrites the slots it does not stream by the wall rule, so nothing a cell needs lives in the ghost columns
 // of a ghost row (MRT.py's left wall reads parked values).
-int enqueue_deep_exchange(lbm_ctx* c, int which, int S) {
-    static const bool skip = std::getenv("LBM_DEBUG_SKIP_EXCHANGE") != nullptr;   // timing diagnostic only: wrong results
-    if (skip) return LBM_OK;
-    const ncclDataType_t dt = c->p.dtype == LBM_F32 ? ncclFloat : ncclDouble;
-    const int ny = c->geo.ny, nplanes = c->p.turb ? Q + 2 : Q;
+//
+// The rows are described once, as blocks of contiguous elements, for RCCL (below) and for the externally driven exchange
+// (lbm_halo_export_rows / lbm_halo_import_rows): [y][k][x] layout: S rows of all planes are ONE block; [k][y][x]: one per plane.
+struct RowBlocks {
+    int n = 0;
+    char* ptr[Q + 2];
+    size_t elems = 0;   // per block
+};
+RowBlocks deep_blocks(lbm_ctx* c, int which, int r0, int S) {
+    RowBlocks b;
+    const int nplanes = c->p.turb ? Q + 2 : Q;
     const bool rows_layout = c->geo.row != c->geo.pitch;
-    auto block = [&](int r0, int k) {
-        return (char*)c->lat[which] + ((size_t)k * c->geo.plane + (size_t)(r0 + GHY) * c->geo.row) * c->es;
-    };
+    auto at = [&](int k) { return (char*)c->lat[which] + ((size_t)k * c->geo.plane + (size_t)(r0 + GHY) * c->geo.row) * c->es; };
+    if (rows_layout) {
+        b.n = 1; b.ptr[0] = at(0); b.elems = (size_t)S * c->geo.row;
+    } else {
+        b.n = nplanes; b.elems = (size_t)S * c->geo.pitch;
+        for (int k = 0; k < nplanes; ++k) b.ptr[k] = at(k);
+    }
+    return b;
+}
+int deep_send_row0(const lbm_ctx* c, int side, int S) { return side == LBM_SIDE_LOW ? 0 : c->geo.ny - S; }
+int deep_recv_row0(const lbm_ctx* c, int side, int S) { return side == LBM_SIDE_LOW ? -S : c->geo.ny; }
+
+int enqueue_deep_exchange(lbm_ctx* c, int which, int S) {
+    if (debug_skip_exchange()) return LBM_OK;
+    const ncclDataType_t dt = c->p.dtype == LBM_F32 ? ncclFloat : ncclDouble;
     NCCL_TRY(c, rccl().GroupStart());
     for (int side = 0; side < 2; ++side) {
         int peer = side == LBM_SIDE_LOW ? c->rank - 1 : c->rank + 1;
         if (c->loopback) peer = 0;
         if (!has_neighbour(c, side)) continue;
         const int sside = c->loopback ? (side ^ 1) : side;   // see enqueue_exchange
-        const int send_r0 = sside == LBM_SIDE_LOW ? 0 : ny - S;
-        const int recv_r0 = side == LBM_SIDE_LOW ? -S : ny;
-        if (rows_layout) {   // [y][k][x]: S rows of all planes are one contiguous block
-            const size_t n = (size_t)S * c->geo.row;
-            NCCL_TRY(c, rccl().Send(block(send_r0, 0), n, dt, peer, c->comm, c->s_comm));
-            NCCL_TRY(c, rccl().Recv(block(recv_r0, 0), n, dt, peer, c->comm, c->s_comm));
-        } else {
-            const size_t n = (size_t)S * c->geo.pitch;
-            for (int k = 0; k < nplanes; ++k) {
-                NCCL_TRY(c, rccl().Send(block(send_r0, k), n, dt, peer, c->comm, c->s_comm));
-                NCCL_TRY(c, rccl().Recv(block(recv_r0, k), n, dt, peer, c->comm, c->s_comm));
-            }
+        const RowBlocks snd = deep_blocks(c, which, deep_send_row0(c, sside, S), S);
+        const RowBlocks rcv = deep_blocks(c, which, deep_recv_row0(c, side, S), S);
+        for (int i = 0; i < snd.n; ++i) {
+            NCCL_TRY(c, rccl().Send(snd.ptr[i], snd.elems, dt, peer, c->comm, c->s_comm));
+            NCCL_TRY(c, rccl().Recv(rcv.ptr[i], rcv.elems, dt, peer, c->comm, c->s_comm));
         }
     }
     NCCL_TRY(c, rccl().GroupEnd());
     return LBM_OK;
 }
 
-// Every step unit (one single step or one multi-step) between slabs follows one protocol on the two streams:
-//   s_comm    (highest priority): waits ev_int (interior work of the previous unit), runs the wall / slab-edge work of
-//                                 this unit and the RCCL exchanges, records ev_edges;
+// Every launch unit (one single step or one multi-step) of a slab follows one protocol on the two streams:
+//   s_comm    (highest priority): [the unit's halo exchange -- RCCL, or nothing when the caller has moved the rows] ->
+//                                 waits ev_int (bulk kernel of the previous unit) -> wall / slab-edge work of this unit ->
+//                                 records ev_edges;
 //   s_compute                   : waits ev_edges of the PREVIOUS unit, runs the bulk kernel, records ev_int.
-// The small kernels and the exchange therefore run beside the bulk kernel of the same unit.
-int single_step(lbm_ctx* c, bool* comm_used) {
-    const int ny = c->geo.ny;
-    if (c->nranks > 1 || c->loopback) {
-        // edge rows 0 and ny-1 + exchange of the rows just written (the halo of the next step) | interior rows
-        HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
-        if (!c->raw[c->cur] && !c->halo_pending) {   // e.g. a communicator attached to a lattice already stepped
-            int rc = enqueue_exchange(c, c->cur);
+// The exchange of a unit is enqueued first: it only touches rows that the edge / frame kernels of the previous unit wrote
+// (same stream, in order) and ghost rows, so it runs beside the previous unit's bulk kernel; the small kernels run beside the
+// bulk kernel of the same unit.  Nothing is carried from one unit to the next except thin_valid (a one-row halo that is
+// already in place, e.g. the one lbm_step leaves for lbm_get_fields).
+int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
+    const int ny = c->geo.ny, a = c->cur, b = c->cur ^ 1;
+    if (is_slab(c)) {
+        // edge rows 0 and ny-1 (they read the ghost rows) | interior rows
+        if (rccl_x && !c->raw[a] && !c->thin_valid) {   // (a raw lattice is not streamed: no halo needed)
+            int rc = enqueue_exchange(c, a);
             if (rc) return rc;
         }
-        int rc = launch_rows(c, 0, ny - 1, 2, c->s_comm);
+        HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+        int rc = launch_rows(c, a, b, 0, ny - 1, 2, c->s_comm);
         if (rc) return rc;
         HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
         HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
-        rc = launch_rows(c, 1, 1, ny - 2, c->s_compute);
+        rc = launch_rows(c, a, b, 1, 1, ny - 2, c->s_compute);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
-        finish_step(c);
-        rc = enqueue_exchange(c, c->cur);
-        if (rc) return rc;
-        c->halo_pending = true;
-        c->deep_rows = 0;
+        finish_unit(c, 1);
         *comm_used = true;
         return LBM_OK;
     }
     if (c->use_tb) HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier multi-step
-    int rc = launch_rows(c, 0, 1, ny, c->s_compute);
+    int rc = launch_rows(c, a, b, 0, 1, ny, c->s_compute);
     if (rc) return rc;
     if (c->use_tb) HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
-    finish_step(c);
+    finish_unit(c, 1);
     return LBM_OK;
 }
 
-// S = c->tb_steps steps: lat[a] (state n) -> lat[b] (state n+S).  Bulk: the deep-interior kernel on cells >= TB_F away
-// from walls and slab edges.  Frame: S ordinary single steps on strips of decreasing width (TB_F + S - i for pass i; pass i+1
+// S steps: lat[a] (state n) -> lat[b] (state n+S).  Bulk: the deep-interior kernel on cells >= tb_f away
+// from walls and slab edges.  Frame: S ordinary single steps on strips of decreasing width (tb_f + S - i for pass i; pass i+1
 // pulls from one cell further out than it writes), through the scratch lattices, the last one into lat[b].
 // Between slabs the frame passes and the exchanges share the second stream, beside the tile kernel.  With the deep halo
-// (MRT_GPU semantics) the row strips of pass i start S - i rows inside the neighbour's rows received before the unit, and the
-// only exchange is the one for the next unit; otherwise every pass is followed by a one-row exchange.  (Running row and
+// (MRT_GPU semantics) the row strips of pass i start S - i rows inside the neighbour's rows received before the unit, and that
+// is the unit's only exchange; otherwise every pass but the last is followed by a one-row exchange.  (Running row and
 // column strips as separate launches on separate streams was measured and lost 8 %: profiles/r01_logs/perf31.log, perf35.log.)
-int multi_step(lbm_ctx* c, bool* comm_used, int S, int S_next) {
-    const bool multi = c->nranks > 1 || c->loopback;
-    if (!multi && c->frame_fused && S >= 3) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
+int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
+    const bool slab = is_slab(c);
+    if (!slab && c->frame_fused && S >= 3) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
         HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // (frame launches of an earlier unit, if any)
         int rc = launch_deep(c, c->cur, c->cur ^ 1, c->s_compute, S, true);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
-        c->cur ^= 1;
-        c->raw[c->cur] = 0;
-        c->nsteps += S;
+        finish_unit(c, S);
         return LBM_OK;
     }
-    const bool deep = multi && c->deep_halo;
-    const int a = c->cur, b = c->cur ^ 1;   // S: steps of this unit; S_next: of the next one if it is a multi-step too (else 0)
-    HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
-    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // this unit's tile kernel needs the previous unit's frame
+    const bool deep = slab && c->deep_halo;
+    if (slab && !deep && !rccl_x) return fail(c, LBM_ERR_STATE, "a multi-step unit of a slab needs the deep halo (MRT_GPU semantics) or the in-library exchange");
+    const int a = c->cur, b = c->cur ^ 1;
     int rc;
-    int from = a;
-    if (multi && (deep ? c->deep_rows < S : !c->halo_pending)) {
+    if (slab && rccl_x && (deep || !c->thin_valid)) {
         rc = deep ? enqueue_deep_exchange(c, a, S) : enqueue_exchange(c, a);
         if (rc) return rc;
     }
+    HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // this unit's tile kernel needs the previous unit's frame
+    int from = a;
     const bool has_lo = has_neighbour(c, LBM_SIDE_LOW), has_hi = has_neighbour(c, LBM_SIDE_HIGH);
-    if (c->frame_fused && S >= 3 && (!multi || deep)) {
+    if (c->frame_fused && S >= 3 && (!slab || deep)) {
         rc = launch_frame_multi(c, a, b, S, c->s_comm, deep && has_lo, deep && has_hi);
         if (rc) return rc;
     } else
@@ -491,7 +533,7 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, int S_next) {
         const int ext = deep ? S - i : 0;
         rc = launch_frame(c, from, to, c->tb_f + S - i, c->s_comm, has_lo ? ext : 0, has_hi ? ext : 0);
         if (rc) return rc;
-        if (multi && !deep && i < S) {
+        if (slab && !deep && i < S) {
             rc = enqueue_exchange(c, to);
             if (rc) return rc;
         }
@@ -501,28 +543,92 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, int S_next) {
     rc = launch_deep(c, a, b, c->s_compute, S);
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
-    c->cur ^= 1;
-    c->raw[c->cur] = 0;
-    c->nsteps += S;
-    if (multi) {   // the halo of the next unit, behind the last row strips and beside this unit's tile kernel
-        const bool deep_next = deep && S_next > 0;
-        rc = deep_next ? enqueue_deep_exchange(c, c->cur, S_next) : enqueue_exchange(c, c->cur);
-        if (rc) return rc;
-        c->halo_pending = true;
-        c->deep_rows = deep_next ? S_next : 0;
-    }
+    finish_unit(c, S);
     *comm_used = true;
     return LBM_OK;
 }
 
-// Steps of the next unit when `left` steps remain.  The first step after an upload reads raw populations, and the LAST step
-// of a call is always a single step (lbm_get_fields needs the lattice of the step before the last for the one-step lag of
-// u / rho); what remains before it goes into one shorter launch of the in-place kernel (same frame width) if that is >= 3 steps.
+// Can the lattice of the step before the last be recomputed after a unit of S steps (lazy lag)?  A lone lattice: always (any
+// number of single or multi-step launches).  A slab: from the deep halo the unit received, with one launch of S - 1 >= 3 steps.
+bool lag_replayable(const lbm_ctx* c, int S) {
+    if (S <= 1) return true;
+    if (!c->lazy_lag || c->push) return false;
+    if (!is_slab(c)) return true;
+    return c->deep_halo && S - 1 >= 3;
+}
+
+// Steps of the next unit when `left` steps remain.  The first step after an upload reads raw populations (a single step).
+// A unit is at most tb_steps long and at least `min_unit` (3: the in-place kernel's minimum; 4 on slabs so that the last unit
+// of a call can be replayed for the one-step lag of u / rho; 2 for the two-phase kernel); what is left below that goes in
+// single steps.  LBM_FLAG_EAGER_LAG (and slabs that cannot replay): the LAST step of a call is always a single step.
 int unit_steps(const lbm_ctx* c, int left, bool raw) {
-    if (!c->use_tb || raw || left < 1) return left < 1 ? 0 : 1;
-    if (left >= c->tb_steps + 1) return c->tb_steps;
-    if (c->tb_steps >= 3 && left - 1 >= 3) return left - 1;
-    return 1;
+    if (left < 1) return 0;
+    if (!c->use_tb || raw) return 1;
+    const int T = c->tb_steps;
+    if (is_slab(c) && !c->deep_halo && !own_transport(c)) return 1;   // (per-pass exchanges cannot be driven from outside)
+    if (!lag_replayable(c, T)) {
+        if (left >= T + 1) return T;
+        if (T >= 3 && left - 1 >= 3) return left - 1;
+        return 1;
+    }
+    if (T == 2) return left >= 2 ? 2 : 1;
+    const int m = is_slab(c) ? 4 : 3;
+    if (left >= T) {
+        const int r = left - T;
+        if (r == 0 || r >= m) return T;
+        if (left - m >= m) return left - m;     // e.g. 8 = 4 + 4 instead of 5 + 3 singles
+        return T;
+    }
+    return left >= m ? left : 1;
+}
+
+// Recompute the lattice of the step before the last into lat[LAT_LAG] (see lbm_ctx::lag); returns the index of the lattice
+// whose gathered populations are the state the LAST iteration started from.
+int prev_lattice(lbm_ctx* c, int* which) {
+    if (c->nsteps == 0) { *which = c->cur; return LBM_OK; }
+    if (c->lag == 0) { *which = c->cur ^ 1; return LBM_OK; }
+    *which = LAT_LAG;
+    if (c->lag_valid) return LBM_OK;
+    if (!c->lat[LAT_LAG]) {
+        hipError_t e = hipMalloc(&c->lat[LAT_LAG], c->lat_bytes);
+        if (e != hipSuccess) return fail(c, LBM_ERR_NOMEM, std::string("hipMalloc(lag lattice): ") + hipGetErrorString(e));
+        HIP_TRY(c, hipMemsetAsync(c->lat[LAT_LAG], 0, c->lat_bytes, c->s_compute));
+    }
+    const int k = c->lag, from = c->cur ^ 1;
+    const bool slab = is_slab(c);
+    int rc;
+    if (k >= 3 && c->tb_steps >= 3) {   // one multi-step launch of k steps (a slab: from the deep halo still in lat[from]'s ghost rows)
+        if (!slab && c->frame_fused) {
+            rc = launch_deep(c, from, LAT_LAG, c->s_compute, k, true);
+        } else {
+            const bool lo = has_neighbour(c, LBM_SIDE_LOW), hi = has_neighbour(c, LBM_SIDE_HIGH);
+            if (c->frame_fused) rc = launch_frame_multi(c, from, LAT_LAG, k, c->s_compute, lo, hi);
+            else {
+                rc = LBM_OK;
+                int f = from;
+                for (int i = 1; i <= k && rc == LBM_OK; ++i) {
+                    const int to = i == k ? LAT_LAG : 2 + ((i - 1) & 1);
+                    rc = launch_frame(c, f, to, c->tb_f + k - i, c->s_compute, lo ? k - i : 0, hi ? k - i : 0);
+                    f = to;
+                }
+            }
+            if (rc == LBM_OK) rc = launch_deep(c, from, LAT_LAG, c->s_compute, k);
+        }
+        if (rc) return rc;
+    } else {                            // k single steps (a lone lattice), through scratch lattice 2
+        if (slab) return fail(c, LBM_ERR_STATE, "internal: the last unit of a slab cannot be replayed");
+        int f = from;
+        for (int i = 1; i <= k; ++i) {
+            const int to = i == k ? LAT_LAG : (f == 2 ? 3 : 2);
+            c->raw[to] = 0;
+            rc = launch_rows(c, f, to, 0, 1, c->geo.ny, c->s_compute);
+            if (rc) return rc;
+            f = to;
+        }
+    }
+    c->raw[LAT_LAG] = 0;
+    c->lag_valid = true;
+    return LBM_OK;
 }
 
 // One step of the push scheme: collide-and-push lat[cur] -> ftemp (lat[2]); wall rules on ftemp + copy -> lat[cur ^ 1].
@@ -537,7 +643,7 @@ int push_step(lbm_ctx* c) {
                            (R*)c->lat[c->cur ^ 1], c->geo, (R)c->p.uLB);
     });
     HIP_TRY(c, hipGetLastError());
-    finish_step(c);
+    finish_unit(c, 1);
     return LBM_OK;
 }
 
@@ -545,6 +651,13 @@ int push_step(lbm_ctx* c) {
 int push_reset(lbm_ctx* c) {
     if (!c->push) return LBM_OK;
     HIP_TRY(c, hipMemcpyAsync(c->lat[2], c->lat[0], (size_t)c->bstride * c->es, hipMemcpyDeviceToDevice, c->s_compute));
+    return LBM_OK;
+}
+
+// later single-stream work (export, timing event, externally driven calls) must see the s_comm results
+int join_comm(lbm_ctx* c) {
+    HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
+    HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_halo, 0));
     return LBM_OK;
 }
 
@@ -556,26 +669,27 @@ int step_many(lbm_ctx* c, int nsteps) {
         }
         return LBM_OK;
     }
+    const bool slab = is_slab(c);
+    if (slab && !own_transport(c))
+        return fail(c, LBM_ERR_STATE, "lbm_step on a slab without a communicator: its ghost rows would never be exchanged (attach one with "
+                                      "lbm_comm_init, or drive the slab with lbm_step_edges/interior/finish, lbm_step_unit and the lbm_halo_* calls)");
     bool comm_used = false;
-    if (c->use_tb || c->nranks > 1 || c->loopback)   // (a lone slab stepping one step per launch uses one stream, no events)
+    if (c->use_tb || slab)   // (a lone lattice stepping one step per launch uses one stream, no events)
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier calls)
     int left = nsteps;
     while (left > 0) {
         const int S = unit_steps(c, left, c->raw[c->cur] != 0);
-        int rc;
-        if (S > 1) {
-            const int S_next = unit_steps(c, left - S, false);
-            rc = multi_step(c, &comm_used, S, S_next > 1 ? S_next : 0);
-        } else {
-            rc = single_step(c, &comm_used);
-        }
+        const int rc = S > 1 ? multi_step(c, &comm_used, S, true) : single_step(c, &comm_used, true);
         if (rc) return rc;
         left -= S;
     }
-    if (comm_used) {   // later single-stream work (export, timing event, split-step API) must see the s_comm results
-        HIP_TRY(c, hipEventRecord(c->ev_halo, c->s_comm));
-        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_halo, 0));
+    if (slab && nsteps > 0 && !c->raw[c->cur]) {   // the populations lbm_get_fields returns for the slab's first / last row need the one-row halo
+        const int rc = enqueue_exchange(c, c->cur);
+        if (rc) return rc;
+        c->thin_valid = true;
+        comm_used = true;
     }
+    if (comm_used) return join_comm(c);
     return LBM_OK;
 }
 
@@ -640,13 +754,46 @@ template <typename R>
 int export_macro_t(lbm_ctx* c) {
     const dim3 g = grid_tiles<R>(c);
     // the fields of the LAST iteration are the moments of the state that iteration started
-    // from, i.e. of the previous lattice (still intact: a step only reads it)
-    const int which = c->nsteps > 0 ? (c->cur ^ 1) : c->cur;
+    // from, i.e. of the previous lattice (prev_lattice: still intact after a single step, recomputed after a multi-step unit)
+    int which = 0;
+    int rc = prev_lattice(c, &which);
+    if (rc) return rc;
     const R* src = (const R*)c->lat[which];
     if (c->p.semantics == LBM_SEM_MRT_PY)
         hipLaunchKernelGGL((k_export_macro<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage, c->bstride);
     else
         hipLaunchKernelGGL((k_export_macro<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, (R*)c->stage, c->bstride);
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+template <typename R>
+int export_tau_t(lbm_ctx* c) {
+    int which = 0;
+    int rc = prev_lattice(c, &which);
+    if (rc) return rc;
+    const R* src = (const R*)c->lat[which];
+    if (c->p.arith == LBM_ARITH_FAST)
+        hipLaunchKernelGGL((k_export_tau<R, true>), grid_tiles<R>(c), dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], relax_of<R>(c->p), batch_of<R>(c), c->p.turb, (R*)c->stage);
+    else
+        hipLaunchKernelGGL((k_export_tau<R, false>), grid_tiles<R>(c), dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], relax_of<R>(c->p), batch_of<R>(c), c->p.turb, (R*)c->stage);
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+constexpr int RED_BLOCKS = 1024;   // partial sums per lattice of lbm_mean_u
+
+template <typename R>
+int reduce_u_t(lbm_ctx* c) {
+    int which = 0;
+    int rc = prev_lattice(c, &which);
+    if (rc) return rc;
+    const R* src = (const R*)c->lat[which];
+    const dim3 g(RED_BLOCKS, 1, c->batch);
+    if (c->p.semantics == LBM_SEM_MRT_PY)
+        hipLaunchKernelGGL((k_reduce_u<R, SEM_PY>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, c->bstride, c->red_dev);
+    else
+        hipLaunchKernelGGL((k_reduce_u<R, SEM_GPU>), g, dim3(BLK), 0, c->s_compute, src, c->geo, c->raw[which], (R)c->p.uLB, c->bstride, c->red_dev);
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
 }
@@ -687,6 +834,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->batch < 0 || p->batch > 65535) return bail("batch must be 0 .. 65535");
     if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return bail("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
     if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return bail("a batch of lattices cannot be slab-decomposed");
+    if (p->ny_local_min < 0 || p->ny_local_min > p->ny_local) return bail("ny_local_min must be 0 or the smallest ny_local of all ranks (<= ny_local)");
+    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > 5)) return bail("tb_steps must be 0 (default) or 2 .. 5");
+    if (p->frame_seg != 0 && p->frame_seg < 8) return bail("frame_seg must be 0 (default) or >= 8");
+    if ((p->flags & LBM_FLAG_NT_ON) && (p->flags & LBM_FLAG_NT_OFF)) return bail("LBM_FLAG_NT_ON and LBM_FLAG_NT_OFF exclude each other");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return bail(std::string("no HIP device: ") + hipGetErrorString(e));
@@ -713,24 +864,30 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     c->batch = p->batch > 1 ? p->batch : 1;
     c->bstride = (long long)nplanes * c->geo.pitch * (p->ny_local + 2 * GHY);   // lattice z of a batch starts z * bstride elements in
     const size_t bytes = (size_t)c->bstride * c->batch * c->es;
+    c->lat_bytes = bytes;
     {
+        // The launch plan.  Everything that shapes the exchange protocol between slabs (several steps per launch or not, how
+        // many, frame width, deep halo) is derived from ny_plan = the smallest slab of the decomposition, never from this
+        // rank's own share of the rows: neighbours must post matching send / receive sequences (lbm_comm_init cross-checks).
+        const int ny_plan = p->ny_local_min > 0 ? p->ny_local_min : p->ny_local;
+        const bool slab = p->y0 > 0 || p->y0 + p->ny_local < p->ny;
         const int V = 16 / c->es;
         const bool can_vec = p->semantics == LBM_SEM_MRT_GPU && p->nx % V == 0;
         if (p->kernel == LBM_KERNEL_VEC && !can_vec) return (delete c, bail("kernel = VEC needs MRT_GPU semantics and nx % (16 / sizeof(real)) == 0"));
         c->push = p->kernel == LBM_KERNEL_PUSH;
         c->use_vec = can_vec && p->kernel != LBM_KERNEL_GENERIC && !c->push;
-        const bool can_tb = p->nx % V == 0 && p->nx >= 32 && p->ny_local >= 32;
-        if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32"));
-        // measured crossover: with one launch per frame pass (batches, LBM_FRAME_FUSED=0) a multi-step pays from ~768^2 cells
+        const bool can_tb = p->nx % V == 0 && p->nx >= 32 && ny_plan >= 32;
+        if (p->kernel == LBM_KERNEL_TB && !can_tb) return (delete c, bail("kernel = TB needs nx % (16 / sizeof(real)) == 0, nx >= 32 and ny_local >= 32 (on every rank)"));
+        // measured crossover: with one launch per frame pass (batches, LBM_FLAG_FRAME_UNFUSED) a multi-step pays from ~768^2 cells
         // (profiles/r01_logs/perf4.log); with the frame inside the tile launch a unit is ONE launch and wins from the smallest
         // lattices the in-place kernel takes (perf41.log, perf43.log: 160^2 4.1-4.5 us per step against 5.1 one step per launch)
-        const bool one_launch = c->batch == 1 && p->ny_local == p->ny && !(std::getenv("LBM_FRAME_FUSED") && std::atoi(std::getenv("LBM_FRAME_FUSED")) == 0);
-        const bool big = one_launch ? (p->nx >= 64 && p->ny_local >= 64)
-                                    : (long long)p->nx * p->ny_local * c->batch >= 768LL * 768LL;
+        const bool unfused = (p->flags & LBM_FLAG_FRAME_UNFUSED) != 0;
+        const bool one_launch = c->batch == 1 && !slab && !unfused;
+        const bool big = one_launch ? (p->nx >= 64 && ny_plan >= 64)
+                                    : (long long)p->nx * ny_plan * c->batch >= 768LL * 768LL;
         c->use_tb = can_tb && (p->kernel == LBM_KERNEL_TB || (p->kernel == LBM_KERNEL_AUTO && big));
         // Steps per launch: the in-place LDS tile kernel with S = 4 (fp32) or 3 (fp64), also with the Smagorinsky closure (its
-        // history is cell-local and stays in registers).  LBM_TB_STEPS=2..5 overrides (A/B, tests; 2 = the two-phase kernel).
-        const char* ts = std::getenv("LBM_TB_STEPS");
+        // history is cell-local and stays in registers).  lbm_params.tb_steps = 2..5 overrides (A/B, tests; 2 = the two-phase kernel).
         // measured in the full stepper (profiles/r01_logs/perf11.log, perf17.log, perf18.log), 4096^2 MRT: fp32 two steps 140,
         // three 176, four 207, five 207 GLUPS; fp64 two 75, three 99 (its x rim of V = 2 cells allows no more)
         // with the closure (perf23.log, 4096^2 fp32, S = 2 / 3 / 4): SRT 108 / 150 / 162, TRT 110 / 145 / 124 (S = 4 spills
@@ -747,32 +904,27 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const int want64 = p->collision == LBM_MRT ? (fast ? 5 : 3) : 4;
         // a lone small lattice is bound by the launch, not by arithmetic or bandwidth: more steps per launch whatever the operator
         // (perf52.log, strict: 160^2 fp32 4.33 -> 4.13 us per step with five, fp64 5.02 -> 4.65 with four)
-        const bool small_lone = one_launch && (long long)p->nx * p->ny_local <= 512LL * 512;
-        const int want = ts ? std::atoi(ts) : small_lone ? (p->dtype == LBM_F32 ? 5 : std::max(4, want64))
-                                                         : (p->dtype == LBM_F32 ? want32 : want64);
-        const bool deep_ok = p->nx >= 64 && p->ny_local >= 64;
+        const bool small_lone = one_launch && (long long)p->nx * ny_plan <= 512LL * 512;
+        const int want = p->tb_steps ? p->tb_steps : small_lone ? (p->dtype == LBM_F32 ? 5 : std::max(4, want64))
+                                                                : (p->dtype == LBM_F32 ? want32 : want64);
+        const bool deep_ok = p->nx >= 64 && ny_plan >= 64;
         c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
         c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
         // tile shape of the three-step kernel, A/B in one run (profiles/r01_logs/perf14.log): 14 vectors x 28 rows beats
         // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  (The wide variant is no longer compiled.)
-        const char* ff = std::getenv("LBM_FRAME_FUSED");
         // measured (profiles/r01_logs/perf37.log, perf38.log): one launch per unit instead of S + 1 and no cross-stream dependency:
         // 4096^2 fp32 278 -> 294 GLUPS, 1024^2 fp64 67 -> 91, 1024^2 fp32 96 -> 135; a batch of 64 x 384^2 loses 5 % (its many
         // short frame workgroups do better as separate small launches), so batches keep one launch per pass
-        c->frame_fused = !(ff && std::atoi(ff) == 0) && (c->batch == 1 || (ff && std::atoi(ff) == 2));   // (2: also for batches, A/B)
+        c->frame_fused = !unfused && (c->batch == 1 || (p->flags & LBM_FLAG_FRAME_FUSED_BATCH));
         // cells of the frame per workgroup (perf43.log): short segments finish a pass in one sweep of the workgroup and suit
         // lattices whose launch is over when the frame chain is (160^2: 4.1 us per step with 16, 6.3 with 64); long ones compute
         // less overlap and suit large lattices (2048^2: 244 GLUPS with 64, 215 with 16)
-        const long long cells1 = (long long)p->nx * p->ny_local;
-        c->frame_seg = cells1 <= 512LL * 512 ? 16 : (cells1 <= 1024LL * 1024 ? 32 : 64);
-        const char* fs = std::getenv("LBM_FRAME_SEG");
-        if (fs && std::atoi(fs) >= 8) c->frame_seg = std::atoi(fs);
-        const char* fl = std::getenv("LBM_FRAME_LDS");
-        c->frame_lds = !(fl && std::atoi(fl) == 0);
-        const char* dh = std::getenv("LBM_DEEP_HALO");
-        c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(dh && std::atoi(dh) == 0);
-        const char* nt = std::getenv("LBM_NT");
-        c->use_nt = nt ? (std::atoi(nt) != 0) : (bytes > ((size_t)192 << 20));
+        const long long cells1 = (long long)p->nx * ny_plan;
+        c->frame_seg = p->frame_seg ? p->frame_seg : (cells1 <= 512LL * 512 ? 16 : (cells1 <= 1024LL * 1024 ? 32 : 64));
+        c->frame_lds = !(p->flags & LBM_FLAG_NO_FRAME_LDS);
+        c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_DEEP_HALO);
+        c->use_nt = (p->flags & LBM_FLAG_NT_ON) ? true : (p->flags & LBM_FLAG_NT_OFF) ? false : (bytes > ((size_t)192 << 20));
+        c->lazy_lag = !(p->flags & LBM_FLAG_EAGER_LAG);
     }
     auto cleanup = [&](const std::string& m) -> lbm_ctx* { lbm_destroy(c); return bail(m); };
     if ((e = hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
@@ -780,8 +932,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // thousands of workgroups of the interior kernel they are meant to overlap
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char* pr = std::getenv("LBM_COMM_PRIORITY");   // A/B: 0 = same priority as the compute stream
-        if (pr && std::atoi(pr) == 0) hi = lo;
+        if (p->flags & LBM_FLAG_COMM_PRIORITY_OFF) hi = lo;   // A/B: same priority as the compute stream
         if ((e = hipStreamCreateWithPriority(&c->s_comm, hipStreamNonBlocking, hi)) != hipSuccess) return cleanup("hipStreamCreate");
     }
     if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
@@ -811,8 +962,9 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->s_compute) (void)hipStreamSynchronize(c->s_compute);
     if (c->s_comm) (void)hipStreamSynchronize(c->s_comm);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NLAT; ++i)
         if (c->lat[i]) (void)hipFree(c->lat[i]);
+    if (c->red_dev) (void)hipFree(c->red_dev);
     if (c->stage) (void)hipFree(c->stage);
     if (c->relax_dev) (void)hipFree(c->relax_dev);
     if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);
@@ -832,7 +984,7 @@ int lbm_init_equilibrium(lbm_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->p.device));
     int rc = sync_all(c);
     if (rc) return rc;
-    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_rows = 0;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->lag = 0; c->lag_valid = false; c->thin_valid = false;
     const dim3 g = grid_rows(c, c->geo.ny);
     if (c->p.dtype == LBM_F32)
         hipLaunchKernelGGL((k_init<float>), g, dim3(BLK), 0, c->s_compute, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
@@ -851,7 +1003,7 @@ int lbm_set_state(lbm_ctx* c, const void* fin_host, int host_dtype) {
     if (rc) return rc;
     rc = host_to_stage(c, fin_host, host_dtype, Q * c->batch);   // [B][9][nx][ny] is B * 9 planes
     if (rc) return rc;
-    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->halo_pending = false; c->deep_rows = 0;
+    c->cur = 0; c->raw[0] = 1; c->raw[1] = 1; c->nsteps = 0; c->lag = 0; c->lag_valid = false; c->thin_valid = false;
     if (c->p.dtype == LBM_F32)
         hipLaunchKernelGGL((k_import<float>), grid_tiles<float>(c), dim3(BLK), 0, c->s_compute, (const float*)c->stage, (float*)c->lat[0], c->geo, (float)c->p.uLB, c->p.turb, c->bstride);
     else
@@ -892,6 +1044,12 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     return step_many(c, nsteps);
 }
 
+int lbm_next_unit(const lbm_ctx* c, int steps_left) {
+    if (!c || steps_left < 0) return LBM_ERR_INVALID;
+    if (c->push) return steps_left > 0 ? 1 : 0;
+    return unit_steps(c, steps_left, c->raw[c->cur] != 0);
+}
+
 int lbm_sync(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->p.device));
@@ -902,7 +1060,7 @@ int lbm_time_steps(lbm_ctx* c, int nsteps, double* ms) {
     if (!c || nsteps < 0 || !ms) return fail(c, LBM_ERR_INVALID, "lbm_time_steps: bad argument");
     HIP_TRY(c, hipSetDevice(c->p.device));
     HIP_TRY(c, hipEventRecord(c->ev_t0, c->s_compute));
-    int rc = step_many(c, nsteps);
+    int rc = step_many(c, nsteps);   // (joins the communication stream into s_compute before returning)
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_t1, c->s_compute));
     HIP_TRY(c, hipEventSynchronize(c->ev_t1));
@@ -944,6 +1102,40 @@ int lbm_get_fields(lbm_ctx* c, void* u_host, void* rho_host, void* fin_host, int
     return LBM_OK;
 }
 
+int lbm_mean_u(lbm_ctx* c, double* mean_out) {
+    if (!c || !mean_out) return fail(c, LBM_ERR_INVALID, "lbm_mean_u: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    if (!c->red_dev) {
+        hipError_t e = hipMalloc((void**)&c->red_dev, ((size_t)RED_BLOCKS + 1) * c->batch * sizeof(double));
+        if (e != hipSuccess) return fail(c, LBM_ERR_NOMEM, std::string("hipMalloc(reduction): ") + hipGetErrorString(e));
+    }
+    rc = c->p.dtype == LBM_F32 ? reduce_u_t<float>(c) : reduce_u_t<double>(c);
+    if (rc) return rc;
+    double* res = c->red_dev + (size_t)RED_BLOCKS * c->batch;
+    const double scale = 1.0 / (2.0 * (double)c->geo.nx * (double)c->geo.ny);
+    hipLaunchKernelGGL(k_reduce_final, dim3((c->batch + BLK - 1) / BLK), dim3(BLK), 0, c->s_compute, c->red_dev, RED_BLOCKS, c->batch, scale, res);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(mean_out, res, (size_t)c->batch * sizeof(double), hipMemcpyDeviceToHost, c->s_compute));
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return LBM_OK;
+}
+
+int lbm_get_tau(lbm_ctx* c, void* tau_host, int host_dtype) {
+    if (!c || !tau_host || (host_dtype != LBM_F32 && host_dtype != LBM_F64)) return fail(c, LBM_ERR_INVALID, "lbm_get_tau: bad argument");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->geo.nx * c->geo.ny;
+    rc = ensure_stage(c, (size_t)12 * n * c->es * c->batch);
+    if (rc) return rc;
+    rc = c->p.dtype == LBM_F32 ? export_tau_t<float>(c) : export_tau_t<double>(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return stage_to_host(c, c->stage, tau_host, host_dtype, c->batch);
+}
+
 int lbm_halo_elems(const lbm_ctx* c) { return c ? 3 * c->geo.nx : 0; }
 
 int lbm_halo_export(lbm_ctx* c, int side, void* buf) {
@@ -980,20 +1172,62 @@ int lbm_step_edges(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
     if (c->push) return fail(c, LBM_ERR_STATE, "the split-step calls do not apply to kernel = PUSH");
     HIP_TRY(c, hipSetDevice(c->p.device));
-    return launch_rows(c, 0, c->geo.ny - 1, 2, c->s_compute);
+    return launch_rows(c, c->cur, c->cur ^ 1, 0, c->geo.ny - 1, 2, c->s_compute);
 }
 
 int lbm_step_interior(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
     if (c->push) return fail(c, LBM_ERR_STATE, "the split-step calls do not apply to kernel = PUSH");
     HIP_TRY(c, hipSetDevice(c->p.device));
-    return launch_rows(c, 1, 1, c->geo.ny - 2, c->s_compute);
+    return launch_rows(c, c->cur, c->cur ^ 1, 1, 1, c->geo.ny - 2, c->s_compute);
 }
 
 int lbm_step_finish(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
     if (c->push) return fail(c, LBM_ERR_STATE, "the split-step calls do not apply to kernel = PUSH");
-    finish_step(c);
+    finish_unit(c, 1);
+    return LBM_OK;
+}
+
+long long lbm_halo_rows_elems(const lbm_ctx* c, int nrows) {
+    if (!c || nrows < 1 || nrows >= GHY) return 0;
+    return (long long)nrows * (c->p.turb ? Q + 2 : Q) * c->geo.pitch;
+}
+
+namespace {
+int copy_rows(lbm_ctx* c, int side, int nrows, void* buf, bool out) {
+    if (!c || !buf || (side != LBM_SIDE_LOW && side != LBM_SIDE_HIGH) || nrows < 1 || nrows >= GHY || nrows > c->geo.ny)
+        return fail(c, LBM_ERR_INVALID, "lbm_halo_export_rows / lbm_halo_import_rows: bad argument (1 <= nrows <= 5)");
+    if (c->batch > 1) return fail(c, LBM_ERR_STATE, "a batch of lattices has no slab halos");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    const RowBlocks b = deep_blocks(c, c->cur, out ? deep_send_row0(c, side, nrows) : deep_recv_row0(c, side, nrows), nrows);
+    const size_t bytes = b.elems * c->es;
+    for (int i = 0; i < b.n; ++i) {
+        char* p = (char*)buf + (size_t)i * bytes;
+        HIP_TRY(c, hipMemcpyAsync(out ? (void*)p : (void*)b.ptr[i], out ? (const void*)b.ptr[i] : (const void*)p, bytes, hipMemcpyDefault, c->s_compute));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return LBM_OK;
+}
+}  // namespace
+
+int lbm_halo_export_rows(lbm_ctx* c, int side, int nrows, void* buf) { return copy_rows(c, side, nrows, buf, true); }
+int lbm_halo_import_rows(lbm_ctx* c, int side, int nrows, const void* buf) { return copy_rows(c, side, nrows, const_cast<void*>(buf), false); }
+
+int lbm_step_unit(lbm_ctx* c, int S) {
+    if (!c) return LBM_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    if (c->push || !c->use_tb) return fail(c, LBM_ERR_STATE, "lbm_step_unit: this context steps one step per launch (lbm_next_unit() is 1)");
+    if (own_transport(c)) return fail(c, LBM_ERR_STATE, "lbm_step_unit: a communicator is attached, lbm_step() moves the halos itself");
+    if (c->raw[c->cur]) return fail(c, LBM_ERR_STATE, "lbm_step_unit: the first step after an upload is a single step");
+    const bool ok = c->tb_steps == 2 ? S == 2 : (S >= 3 && S <= c->tb_steps);
+    if (!ok) return fail(c, LBM_ERR_INVALID, "lbm_step_unit: unit_steps must be 3 .. the context's steps per launch (lbm_next_unit)");
+    if (is_slab(c) && !c->deep_halo) return fail(c, LBM_ERR_STATE, "lbm_step_unit on a slab needs the deep halo (MRT_GPU semantics)");
+    bool comm_used = false;
+    HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far, the imported rows included
+    int rc = multi_step(c, &comm_used, S, false);
+    if (rc) return rc;
+    if (comm_used) return join_comm(c);
     return LBM_OK;
 }
 
@@ -1011,6 +1245,10 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     if (!c || !uid128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, LBM_ERR_INVALID, "lbm_comm_init: bad argument");
     if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
     if (c->batch > 1 || c->push) return fail(c, LBM_ERR_STATE, "a batch of lattices / kernel = PUSH cannot be slab-decomposed");
+    // rank r holds the r-th slab from the lid: the exchange partners are rank - 1 / rank + 1
+    if ((rank > 0) != has_neighbour(c, LBM_SIDE_LOW) || (rank < nranks - 1) != has_neighbour(c, LBM_SIDE_HIGH))
+        return fail(c, LBM_ERR_INVALID, "lbm_comm_init: rank 0 must hold the slab at the lid (y0 = 0), the last rank the one at the bottom wall, "
+                                        "every other rank a slab in between");
     if (!rccl().ok) return fail(c, LBM_ERR_COMM, rccl().err);
     HIP_TRY(c, hipSetDevice(c->p.device));
     ncclUniqueId id;
@@ -1018,8 +1256,49 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
     NCCL_TRY(c, rccl().CommInitRank(&c->comm, nranks, id, rank));
     c->nranks = nranks;
     c->rank = rank;
-    c->halo_pending = false;
-    c->deep_rows = 0;
+    c->thin_valid = false;
+    if (nranks > 1) {
+        // Neighbours must run the same launch plan (they post matching send / receive sequences): compare it once.
+        constexpr int NW = 16;
+        const int32_t mine[NW] = {LBM_ABI_VERSION, c->p.nx, c->p.ny, c->p.dtype, c->p.semantics, c->p.turb, c->geo.pitch,
+                                  c->geo.row != c->geo.pitch ? 1 : 0, c->use_tb ? 1 : 0, c->tb_steps, c->tb_f, c->deep_halo ? 1 : 0,
+                                  c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->p.collision, c->p.arith};
+        int32_t* dev = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&dev, 3 * NW * sizeof(int32_t)));
+        hipError_t e = hipMemcpy(dev, mine, sizeof(mine), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(dev + NW, 0xff, 2 * NW * sizeof(int32_t));
+        if (e != hipSuccess) { (void)hipFree(dev); return fail(c, LBM_ERR_HIP, std::string("lbm_comm_init: ") + hipGetErrorString(e)); }
+        ncclResult_t r = rccl().GroupStart();
+        for (int side = 0; side < 2 && r == ncclSuccess; ++side) {
+            if (!has_neighbour(c, side)) continue;
+            const int peer = side == LBM_SIDE_LOW ? rank - 1 : rank + 1;
+            r = rccl().Send(dev, NW, ncclInt32, peer, c->comm, c->s_comm);
+            if (r == ncclSuccess) r = rccl().Recv(dev + (1 + side) * NW, NW, ncclInt32, peer, c->comm, c->s_comm);
+        }
+        if (r == ncclSuccess) r = rccl().GroupEnd();
+        int32_t theirs[2 * NW];
+        if (r == ncclSuccess) {
+            e = hipStreamSynchronize(c->s_comm);
+            if (e == hipSuccess) e = hipMemcpy(theirs, dev + NW, sizeof(theirs), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(dev);
+        if (r != ncclSuccess) return fail(c, LBM_ERR_COMM, std::string("lbm_comm_init (plan check): ") + rccl().GetErrorString(r));
+        if (e != hipSuccess) return fail(c, LBM_ERR_HIP, std::string("lbm_comm_init (plan check): ") + hipGetErrorString(e));
+        static const char* what[NW] = {"ABI version", "nx", "ny", "dtype", "semantics", "turb", "row pitch", "layout", "steps-per-launch path",
+                                       "steps per launch", "frame width", "deep halo", "fused frame", "lazy lag", "collision", "arith"};
+        for (int side = 0; side < 2; ++side) {
+            if (!has_neighbour(c, side)) continue;
+            for (int i = 0; i < NW; ++i)
+                if (theirs[side * NW + i] != mine[i]) {
+                    (void)rccl().CommDestroy(c->comm);
+                    c->comm = nullptr; c->nranks = 1; c->rank = 0;
+                    return fail(c, LBM_ERR_STATE, std::string("lbm_comm_init: rank ") + std::to_string(side == LBM_SIDE_LOW ? rank - 1 : rank + 1) +
+                                                  " runs a different launch plan (" + what[i] + ": " + std::to_string(theirs[side * NW + i]) + " there, " +
+                                                  std::to_string(mine[i]) + " here); create every rank with the same parameters and "
+                                                  "lbm_params.ny_local_min = the smallest slab");
+                }
+        }
+    }
     return LBM_OK;
 }
 
@@ -1028,9 +1307,6 @@ int lbm_comm_loopback(lbm_ctx* c) {
     if (c->comm) return fail(c, LBM_ERR_STATE, "communicator already attached");
     if (c->geo.y0 == 0 || c->geo.y0 + c->geo.ny == c->geo.NY)
         return fail(c, LBM_ERR_INVALID, "lbm_comm_loopback needs a slab that touches neither the lid nor the bottom wall");
-    const char* ls = std::getenv("LBM_DEBUG_LOOPBACK_SIDES");
-    c->loop_sides = ls ? (std::atoi(ls) & 3) : 3;
-    if (c->loop_sides == 0) return fail(c, LBM_ERR_INVALID, "LBM_DEBUG_LOOPBACK_SIDES must be 1, 2 or 3");
     if (!rccl().ok) return fail(c, LBM_ERR_COMM, rccl().err);
     HIP_TRY(c, hipSetDevice(c->p.device));
     ncclUniqueId id;
@@ -1039,8 +1315,7 @@ int lbm_comm_loopback(lbm_ctx* c) {
     c->nranks = 1;
     c->rank = 0;
     c->loopback = true;
-    c->halo_pending = false;
-    c->deep_rows = 0;
+    c->thin_valid = false;
     return LBM_OK;
 }
 

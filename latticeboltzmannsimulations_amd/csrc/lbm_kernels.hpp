@@ -428,4 +428,59 @@ __global__ __launch_bounds__(BLK) void k_export_macro(const R* __restrict__ src,
         }
 }
 
+// lattice -> staging: relaxation time tau + tau_turbulent of the iteration that starts from the populations gathered from `src`
+// (taus_g, MRT_GPU.py:385-387); turb = 0: the constant 1 / omega.  stage = [nx][ny_local]
+template <typename R, bool FAST>
+__global__ __launch_bounds__(BLK) void k_export_tau(const R* __restrict__ src, Geo geo, int raw, Relax<R> w, Batch<R> bt, int turb,
+                                                    R* __restrict__ stage) {
+    constexpr int TRX = trx<R>(), RY = BLK / TRX;
+    __shared__ R t[TRX][33];
+    const long long n = (long long)geo.nx * geo.ny;
+    if (bt.w) { src += blockIdx.z * bt.stride; w = bt.w[blockIdx.z]; }
+    stage += blockIdx.z * n;
+    const int x0 = blockIdx.x * TRX, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x % TRX, x = x0 + tx;
+    for (int ty = threadIdx.x / TRX; ty < 32; ty += RY) {
+        const int y = y0 + ty;
+        if (x >= geo.nx || y >= geo.ny) continue;
+        R tau = (R)1.0 / w.w_nu;
+        if (turb) {
+            R g[Q];
+            gather<R, SEM_GPU>(src, geo, raw, w.uLB, x, y, g);
+            const long long me = geo.at(x, y);
+            tau = smagorinsky_tau<R, FAST>(g, src[K_QEQ * geo.plane + me], src[K_RHO * geo.plane + me], w.w_nu);
+        }
+        t[tx][ty] = tau;
+    }
+    __syncthreads();
+    const int yy = threadIdx.x & 31, xb = threadIdx.x >> 5;
+    for (int xx = xb; xx < TRX; xx += BLK / 32)
+        if (x0 + xx < geo.nx && y0 + yy < geo.ny) stage[(long long)(x0 + xx) * geo.ny + y0 + yy] = t[xx][yy];
+}
+
+// Sum over the slab of ux + uy of the macroscopic state gathered from `src` (what k_export_macro would write), in double:
+// partial[blockIdx.z * gridDim.x + blockIdx.x] = the block's sum; k_reduce_final adds the partial sums of each lattice in
+// index order -- a fixed summation tree, so the result does not vary from run to run.
+template <typename R, int SEM>
+__global__ __launch_bounds__(BLK) void k_reduce_u(const R* __restrict__ src, Geo geo, int raw, R uLB, long long bstride,
+                                                  double* __restrict__ partial) {
+    __shared__ double red[BLK];
+    src += blockIdx.z * bstride;
+    const long long n = (long long)geo.nx * geo.ny;
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) {
+        const int y = (int)(i / geo.nx), x = (int)(i - (long long)y * geo.nx);
+        R g[Q], rho, ux, uy;
+        gather<R, SEM>(src, geo, raw, uLB, x, y, g);
+        macros<R>(g, x, geo.y0 + y, geo.nx, geo.NY, uLB, rho, ux, uy);
+        acc += (double)ux + (double)uy;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = BLK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.z * gridDim.x + blockIdx.x] = red[0];
+}
 

@@ -11,8 +11,8 @@ Two transports drive the same kernels:
 * ``RcclSlab`` -- the production path: the exchange runs inside ``lbm_step`` in C
   (ncclSend/ncclRecv on a second HIP stream, overlapped with the interior rows);
   torch.distributed is used only to hand the ncclUniqueId to every rank.
-* ``HaloDriver`` -- externally driven split step (edges -> interior -> finish, then export ->
-  transport -> import of the rows just written); transports: torch.distributed P2P (gloo with host buffers, or nccl with device
+* ``HaloDriver`` -- the same launch-unit protocol driven from outside (single steps: edges -> interior -> finish around a
+  one-row halo; multi-step units: S complete rows per side, then lbm_step_unit); transports: torch.distributed P2P (gloo with host buffers, or nccl with device
   buffers) and an in-process copy between several slabs on ONE device (``LocalSlabs``).
   Used by the tests (including the CPU gloo tests with a stand-in stepper) and as a
   portable path.
@@ -40,11 +40,63 @@ def neighbours(rank, nslabs):
     return (rank - 1 if rank > 0 else None, rank + 1 if rank < nslabs - 1 else None)
 
 
-class LocalSlabs:
+def min_rows(ny, nslabs):
+    """The smallest slab of partition_rows(ny, nslabs): pass it as `min_rows` to every CavitySolver of the decomposition, so
+    that all of them derive the same launch plan (lbm_params.ny_local_min)."""
+    return min(n for _, n in partition_rows(ny, nslabs))
+
+
+def _next_unit(st, left):
+    """Steps of the next launch unit (steppers without a multi-step path advance one step at a time)."""
+    return st.next_unit(left) if hasattr(st, "next_unit") else 1
+
+
+class _UnitDriver:
+    """The launch-unit schedule of lbm_step(), driven from outside with any transport (subclasses provide exchange() -- the
+    one-row halo of three planes -- and exchange_rows(S) -- S complete rows per side).  Same protocol as the in-library RCCL
+    path: a single step needs a current one-row halo; a unit of S > 1 steps is preceded by ONE exchange of the S complete
+    rows next to each interface and contains no communication (lbm_step_unit); every step() call ends with a one-row
+    exchange so that get_fields() can return the populations of the slabs' first and last rows."""
+
+    def _steppers(self):
+        raise NotImplementedError
+
+    def _plan(self, left):
+        units = {_next_unit(st, left) for st in self._steppers()}
+        if len(units) != 1:
+            raise RuntimeError(f"the slabs disagree on the next launch unit ({sorted(units)}): create them with the same min_rows")
+        return units.pop()
+
+    def step(self, nsteps=1):
+        left = int(nsteps)
+        multi = self._nslabs() > 1
+        while left > 0:
+            S = self._plan(left)
+            if S > 1:
+                if multi:
+                    self.exchange_rows(S)
+                for st in self._steppers():
+                    st.step_unit(S)
+                self._thin = False
+            else:
+                if multi and not self._thin:
+                    self.exchange()
+                for st in self._steppers():
+                    st.step_edges()
+                    st.step_interior()
+                    st.step_finish()
+                self._thin = False
+            left -= S
+        if multi and not self._thin:
+            self.exchange()
+        return self
+
+
+class LocalSlabs(_UnitDriver):
     """Several slabs held by ONE process (e.g. all on one device): the halo of slab i is
-    copied straight from slab i +- 1.  `steppers` expose the split-step primitives of
+    copied straight from slab i +- 1.  `steppers` expose the externally driven primitives of
     CavitySolver (halo_elems / halo_export / halo_import / step_edges / step_interior /
-    step_finish)."""
+    step_finish, and for multi-step units next_unit / halo_rows_elems / halo_export_rows / halo_import_rows / step_unit)."""
 
     def __init__(self, steppers):
         self.s = list(steppers)
@@ -52,8 +104,15 @@ class LocalSlabs:
         dt = self.s[0].dtype
         self._up = [np.empty(n, dtype=dt) for _ in self.s]    # what slab i sends to i-1
         self._down = [np.empty(n, dtype=dt) for _ in self.s]  # what slab i sends to i+1
+        self._thin = False
         if len(self.s) > 1:
             self.exchange()   # slabs that were already stepped get current ghost rows; harmless otherwise
+
+    def _steppers(self):
+        return self.s
+
+    def _nslabs(self):
+        return len(self.s)
 
     def exchange(self):
         S = len(self.s)
@@ -67,21 +126,28 @@ class LocalSlabs:
                 st.halo_import(LOW, self._down[i - 1].ctypes.data)
             if i < S - 1:
                 st.halo_import(HIGH, self._up[i + 1].ctypes.data)
+        self._thin = True
 
-    def step(self, nsteps=1):
-        """Each step is followed by the exchange of the rows it wrote, so that on return every
-        slab's ghost rows are current (get_fields needs them for the populations)."""
-        for _ in range(nsteps):
-            for st in self.s:
-                st.step_edges()
-                st.step_interior()
-                st.step_finish()
-            if len(self.s) > 1:
-                self.exchange()
-        return self
+    def exchange_rows(self, nrows):
+        """The deep halo of a unit of `nrows` steps: the nrows complete rows next to every interface, both ways."""
+        S = len(self.s)
+        dt = self.s[0].dtype
+        n = self.s[0].halo_rows_elems(nrows)
+        up = [np.empty(n, dtype=dt) for _ in self.s]
+        down = [np.empty(n, dtype=dt) for _ in self.s]
+        for i, st in enumerate(self.s):
+            if i > 0:
+                st.halo_export_rows(LOW, nrows, up[i].ctypes.data)
+            if i < S - 1:
+                st.halo_export_rows(HIGH, nrows, down[i].ctypes.data)
+        for i, st in enumerate(self.s):
+            if i > 0:
+                st.halo_import_rows(LOW, nrows, down[i - 1].ctypes.data)
+            if i < S - 1:
+                st.halo_import_rows(HIGH, nrows, up[i + 1].ctypes.data)
 
 
-class HaloDriver:
+class HaloDriver(_UnitDriver):
     """One slab per process, halos moved with torch.distributed point-to-point ops.
 
     backend 'gloo': host staging buffers (works without a GPU for the stand-in stepper and
@@ -93,43 +159,62 @@ class HaloDriver:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.st, self.rank, self.world, self.group = stepper, rank, world, group
-        tdt = torch.float32 if np.dtype(stepper.dtype) == np.float32 else torch.float64
+        self.device = device
+        self.tdt = torch.float32 if np.dtype(stepper.dtype) == np.float32 else torch.float64
         n = stepper.halo_elems()
-        mk = lambda: torch.empty(n, dtype=tdt, device=device)  # noqa: E731
+        mk = lambda: torch.empty(n, dtype=self.tdt, device=device)  # noqa: E731
         self.lo, self.hi = neighbours(rank, world)
         self.send = {LOW: mk(), HIGH: mk()}
         self.recv = {LOW: mk(), HIGH: mk()}
+        self._thin = False
         if world > 1:
             self.exchange()
 
-    def exchange(self):
+    def _steppers(self):
+        return [self.st]
+
+    def _nslabs(self):
+        return self.world
+
+    def _plan(self, left):
+        S = _next_unit(self.st, left)
+        if self.world > 1:     # every rank must take the same unit: they post matching sends / receives
+            t = self.torch.tensor([S, -S], dtype=self.torch.int64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+            if int(t[0]) != S or int(-t[1]) != S:
+                raise RuntimeError("the ranks disagree on the next launch unit: create every slab with the same min_rows")
+        return S
+
+    def _move(self, send, recv, export, imp):
         dist = self.dist
         ops = []
         for side, peer in ((LOW, self.lo), (HIGH, self.hi)):
             if peer is None:
                 continue
-            self.st.halo_export(side, self.send[side].data_ptr())
-            ops.append(dist.P2POp(dist.isend, self.send[side], peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, self.recv[side], peer, group=self.group))
+            export(side, send[side].data_ptr())
+            ops.append(dist.P2POp(dist.isend, send[side], peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, recv[side], peer, group=self.group))
         if ops:
-            if self.send[LOW].is_cuda:
+            if send[LOW].is_cuda:
                 self.torch.cuda.synchronize()
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-            if self.send[LOW].is_cuda:
+            if send[LOW].is_cuda:
                 self.torch.cuda.synchronize()
         for side, peer in ((LOW, self.lo), (HIGH, self.hi)):
             if peer is not None:
-                self.st.halo_import(side, self.recv[side].data_ptr())
+                imp(side, recv[side].data_ptr())
 
-    def step(self, nsteps=1):
-        for _ in range(nsteps):
-            self.st.step_edges()
-            self.st.step_interior()
-            self.st.step_finish()
-            if self.world > 1:
-                self.exchange()
-        return self
+    def exchange(self):
+        self._move(self.send, self.recv, self.st.halo_export, self.st.halo_import)
+        self._thin = True
+
+    def exchange_rows(self, nrows):
+        n = self.st.halo_rows_elems(nrows)
+        mk = lambda: self.torch.empty(n, dtype=self.tdt, device=self.device)  # noqa: E731
+        send, recv = {LOW: mk(), HIGH: mk()}, {LOW: mk(), HIGH: mk()}
+        self._move(send, recv, lambda side, ptr: self.st.halo_export_rows(side, nrows, ptr),
+                   lambda side, ptr: self.st.halo_import_rows(side, nrows, ptr))
 
 
 def attach_rccl(solver, rank, world, group=None):

@@ -28,6 +28,27 @@ def relaxation(Re, ysize, uLB=0.08, omega_eps=1.2, omega_q=1.2):
     return dict(omega=omega, omegam=omegam, omega_e=1.0, omega_eps=omega_eps, omega_q=omega_q)
 
 
+def _tuning(t):
+    """(tb_steps, frame_seg, flags) of lbm_params from a dict of A/B switches (see CavitySolver)."""
+    t = dict(t or {})
+    tb, seg, flags = int(t.pop("tb_steps", 0) or 0), int(t.pop("frame_seg", 0) or 0), 0
+    off = {"deep_halo": L.LBM_FLAG_NO_DEEP_HALO, "frame_fused": L.LBM_FLAG_FRAME_UNFUSED, "frame_lds": L.LBM_FLAG_NO_FRAME_LDS,
+           "comm_priority": L.LBM_FLAG_COMM_PRIORITY_OFF}
+    on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG}
+    for k, bit in off.items():
+        if not t.pop(k, True):
+            flags |= bit
+    for k, bit in on.items():
+        if t.pop(k, False):
+            flags |= bit
+    nt = t.pop("nt", None)
+    if nt is not None:
+        flags |= L.LBM_FLAG_NT_ON if nt else L.LBM_FLAG_NT_OFF
+    if t:
+        raise ValueError(f"unknown tuning switches {sorted(t)}")
+    return tb, seg, flags
+
+
 class CavitySolver:
     """One lattice (or one y-slab of it) resident on one MI355X.
 
@@ -44,10 +65,16 @@ class CavitySolver:
     layout       : device arrays 'planes' [k][y][x], 'rows' [y][k][x], 'auto' (= rows)
     arith        : 'strict' (default; the reference's operation order, bit-identical to the CPU restatement the tests check against) or 'fast' (MRT operator
                    in factored form, about half the arithmetic, agrees to rounding)
+    min_rows     : slabs: the smallest ny_local of ALL slabs of the decomposition (lbm_params.ny_local_min) -- the launch plan is
+                   derived from it, so that neighbours run the same exchange protocol
+    tuning       : A/B switches of the launch plan, none of which changes a result: tb_steps (2..5 steps per launch),
+                   frame_seg, and the boolean flags deep_halo, frame_fused, frame_fused_batch, frame_lds, nt, comm_priority,
+                   eager_lag (lbm_params.tb_steps / frame_seg / flags)
     """
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,
-                 device=0, rows=None, kernel="auto", layout="auto", omega_eps=None, omega_q=None, batch=1, arith="strict"):
+                 device=0, rows=None, kernel="auto", layout="auto", omega_eps=None, omega_q=None, batch=1, arith="strict",
+                 min_rows=None, tuning=None):
         self._h = None
         self.batch = int(batch)
         self._lead = getattr(self, "_lead", ())      # leading axes of the host arrays: (B,) for a CavityBatch
@@ -76,6 +103,9 @@ class CavitySolver:
         p.layout = _LAYOUT[layout]
         p.batch = self.batch
         p.arith = _ARITH[arith]
+        p.ny_local_min = 0 if min_rows is None else int(min_rows)
+        p.tb_steps, p.frame_seg, p.flags = _tuning(tuning)
+        self.turb = int(turb)
         p.uLB = self.uLB
         p.omega, p.omegam = self.relax["omega"], self.relax["omegam"]
         p.omega_e, p.omega_eps, p.omega_q = self.relax["omega_e"], self.relax["omega_eps"], self.relax["omega_q"]
@@ -151,6 +181,13 @@ class CavitySolver:
     def steps_done(self):
         return int(self.lib.lbm_steps_done(self._h))
 
+    def next_unit(self, steps_left):
+        """Time steps the next launch unit of step() advances when `steps_left` remain (1 = a single step)."""
+        n = int(self.lib.lbm_next_unit(self._h, int(steps_left)))
+        if n < 0:
+            raise RuntimeError("lbm_next_unit failed")
+        return n
+
     # -- state out ----------------------------------------------------------------------
     def get_fields(self, want_fin=False, out_dtype=None, u=None, rho=None, fin=None):
         """Returns (u[2,X,Y], rho[X,Y]) (and fin[9,X,Y]).  Arrays are whole-lattice shaped;
@@ -168,20 +205,48 @@ class CavitySolver:
                     "lbm_get_fields")
         return (u, rho, fin) if fin is not None else (u, rho)
 
+    def mean_u(self):
+        """mean(u) of the fields get_fields() would return, reduced on the device in double (lbm_mean_u): one float per
+        lattice crosses PCIe instead of the field.  A batch returns an array [B]."""
+        out = (ctypes.c_double * self.batch)()
+        self._check(self.lib.lbm_mean_u(self._h, out), "lbm_mean_u")
+        return np.array(out[:]) if self._lead else float(out[0])
+
+    def get_tau(self, out_dtype=None):
+        """tau + tau_turbulent per cell of the last iteration (taus_g, MRT_GPU.py:387); 1 / omega everywhere when turb = 0."""
+        dt = self.dtype if out_dtype is None else np.dtype(out_dtype)
+        tau = np.zeros(self._lead + (self.nx, self.ny), dtype=dt)
+        self._check(self.lib.lbm_get_tau(self._h, tau.ctypes.data, _DT[tau.dtype]), "lbm_get_tau")
+        return tau
+
     # -- checkpoint / restart (the reference has neither; SURVEY 8f item 4) -------------------
     def save_checkpoint(self, path):
         """Write the populations and the run parameters to `path` (.npz).  Restarting from it continues bit-identically
         (the state of the scheme is `fin`); with turb = 1 the one-step Smagorinsky history restarts from the state."""
         u, rho, fin = self.get_fields(want_fin=True)
+        path = _npz(path)
         np.savez(path, fin=fin, steps_done=self.steps_done, nx=self.nx, ny=self.ny, Re=self.Re, RT=self.RT, uLB=self.uLB,
-                 semantics=self.semantics, dtype=self.dtype.name, u=u, rho=rho)
+                 semantics=self.semantics, dtype=self.dtype.name, rows=np.array([self.y0, self.ny_local]), turb=self.turb, u=u, rho=rho)
+        return path
 
-    def load_checkpoint(self, path):
-        """Upload the populations of a checkpoint written by save_checkpoint (sizes must match); returns the number of
-        steps the checkpointed run had done."""
-        with np.load(path, allow_pickle=False) as z:
+    def load_checkpoint(self, path, strict=True):
+        """Upload the populations of a checkpoint written by save_checkpoint; returns the number of steps the checkpointed
+        run had done.  The lattice size must match; with `strict` (default) so must dtype, semantics, collision operator,
+        closure and Reynolds number -- a continuation is bit-identical only then.  The array is the whole lattice, so a slab
+        may restart from a checkpoint of the undivided lattice (each context reads its own rows) but not from another slab's."""
+        with np.load(_npz(path), allow_pickle=False) as z:
             if int(z["nx"]) != self.nx or int(z["ny"]) != self.ny:
                 raise ValueError("checkpoint lattice size differs")
+            rows = tuple(int(v) for v in z["rows"]) if "rows" in z else (0, self.ny)
+            if rows != (0, self.ny) and rows != (self.y0, self.ny_local):
+                raise ValueError(f"checkpoint holds rows {rows} only, this context needs {(self.y0, self.ny_local)}")
+            if strict:
+                have = dict(dtype=str(z["dtype"]), semantics=str(z["semantics"]), RT=str(z["RT"]), Re=float(z["Re"]), uLB=float(z["uLB"]),
+                            turb=int(z["turb"]) if "turb" in z else self.turb)
+                want = dict(dtype=self.dtype.name, semantics=self.semantics, RT=self.RT, Re=self.Re, uLB=self.uLB, turb=self.turb)
+                diff = {k: (have[k], want[k]) for k in want if have[k] != want[k]}
+                if diff:
+                    raise ValueError(f"checkpoint was written by a different run (checkpoint, this solver): {diff}")
             self.set_state(np.ascontiguousarray(z["fin"]))
             return int(z["steps_done"])
 
@@ -203,6 +268,19 @@ class CavitySolver:
 
     def step_finish(self):
         self._check(self.lib.lbm_step_finish(self._h), "lbm_step_finish")
+
+    # multi-step launch units between slabs: S complete rows per side before the unit, no communication inside it
+    def halo_rows_elems(self, nrows):
+        return int(self.lib.lbm_halo_rows_elems(self._h, int(nrows)))
+
+    def halo_export_rows(self, side, nrows, ptr):
+        self._check(self.lib.lbm_halo_export_rows(self._h, int(side), int(nrows), ctypes.c_void_p(ptr)), "lbm_halo_export_rows")
+
+    def halo_import_rows(self, side, nrows, ptr):
+        self._check(self.lib.lbm_halo_import_rows(self._h, int(side), int(nrows), ctypes.c_void_p(ptr)), "lbm_halo_import_rows")
+
+    def step_unit(self, unit_steps):
+        self._check(self.lib.lbm_step_unit(self._h, int(unit_steps)), "lbm_step_unit")
 
     def comm_init(self, nranks, rank, uid_bytes):
         buf = ctypes.create_string_buffer(bytes(uid_bytes), 128)
@@ -238,6 +316,12 @@ class CavityBatch(CavitySolver):
         raise NotImplementedError("checkpoint the lattices of a batch one by one through get_fields / set_state")
 
     load_checkpoint = save_checkpoint
+
+
+def _npz(path):
+    """np.savez appends '.npz' to a name without it; use one spelling for writing and reading."""
+    path = str(path)
+    return path if path.endswith(".npz") else path + ".npz"
 
 
 def comm_unique_id():

@@ -126,39 +126,56 @@ def test_multi_step_on_thin_and_wide_lattices(sem, coll, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_two_and_three_steps_per_launch_agree(monkeypatch, dtype):
-    """The interior advances three steps per launch by default (two with LBM_TB_STEPS=2): same bits either way."""
+def test_two_and_three_steps_per_launch_agree(dtype):
+    """The interior advances three to five steps per launch by default (two with tuning tb_steps=2): same bits either way."""
     o = CavityOracleC(132, 99, 400.0, semantics="mrt_gpu", collision="MRT", dtype=dtype).step(47)
-    for steps in ("2", "3", "4", "5"):   # (fp64: the x rim of the tiles is two vectors wide from four steps on)
-        monkeypatch.setenv("LBM_TB_STEPS", steps)
-        with CavitySolver(132, 99, 400.0, RT="MRT", dtype=dtype, kernel="tb") as s:
-            s.step(47)
-            same(s, o, f"LBM_TB_STEPS={steps}")
-    monkeypatch.setenv("LBM_TB_STEPS", "4")
+    for steps in (2, 3, 4, 5):   # (fp64: the x rim of the tiles is two vectors wide from four steps on)
+        for eager in (False, True):     # lazy one-step lag (u / rho recomputed on demand) and a single last step
+            with CavitySolver(132, 99, 400.0, RT="MRT", dtype=dtype, kernel="tb", tuning=dict(tb_steps=steps, eager_lag=eager)) as s:
+                s.step(47)
+                same(s, o, f"tb_steps={steps} eager_lag={eager}")
     for sem, coll in (("mrt_py", "SRT"), ("mrt_gpu", "TRT")):
         o = CavityOracleC(260, 71, 400.0, semantics=sem, collision=coll, dtype=dtype).step(33)
-        with CavitySolver(260, 71, 400.0, RT=coll, semantics=sem, dtype=dtype, kernel="tb") as s:
+        with CavitySolver(260, 71, 400.0, RT=coll, semantics=sem, dtype=dtype, kernel="tb", tuning=dict(tb_steps=4)) as s:
             s.step(33)
             same(s, o, f"four steps {sem} {coll}")
     # the other routes of the frame passes: one launch per pass on the second stream (row strips by vector cells), and the
     # fused passes through scratch lattices instead of LDS windows; segment lengths that do / do not fit the LDS budget
     o = CavityOracleC(260, 131, 400.0, semantics="mrt_gpu", collision="MRT", dtype=dtype).step(27)
-    monkeypatch.delenv("LBM_TB_STEPS")
-    for env in ({"LBM_FRAME_FUSED": "0"}, {"LBM_FRAME_LDS": "0"}, {"LBM_FRAME_SEG": "64"}, {"LBM_FRAME_SEG": "8"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with CavitySolver(260, 131, 400.0, RT="MRT", dtype=dtype, kernel="tb") as s:
+    for tune in (dict(frame_fused=False), dict(frame_lds=False), dict(frame_seg=64), dict(frame_seg=8), dict(nt=True), dict(nt=False)):
+        with CavitySolver(260, 131, 400.0, RT="MRT", dtype=dtype, kernel="tb", tuning=tune) as s:
             s.step(27)
-            same(s, o, f"{env}")
-        for k in env:
-            monkeypatch.delenv(k)
+            same(s, o, f"{tune}")
     # with the Smagorinsky closure: two-phase kernel (history through LDS) and in-place kernel (history in registers)
     o = CavityOracleC(132, 99, 5000.0, semantics="mrt_gpu", collision="MRT", dtype=dtype, turb=1).step(29)
-    for steps in ("2", "3", "4", "5"):
-        monkeypatch.setenv("LBM_TB_STEPS", steps)
-        with CavitySolver(132, 99, 5000.0, RT="MRT", dtype=dtype, turb=1, kernel="tb") as s:
+    for steps in (2, 3, 4, 5):
+        with CavitySolver(132, 99, 5000.0, RT="MRT", dtype=dtype, turb=1, kernel="tb", tuning=dict(tb_steps=steps)) as s:
             s.step(29)
-            same(s, o, f"turb LBM_TB_STEPS={steps}")
+            same(s, o, f"turb tb_steps={steps}")
+
+
+@pytest.mark.parametrize("dtype,coll,turb", [(np.float32, "MRT", 0), (np.float64, "SRT", 1), (np.float64, "MRT", 0)])
+def test_one_step_lag_after_every_kind_of_last_unit(dtype, coll, turb):
+    """lbm_get_fields returns the u / rho computed in the LAST iteration.  After a multi-step launch unit
+    the lattice that iteration started from is recomputed on demand; every call length 1 .. 14 (last unit: single step,
+    3-, 4-, 5-step launch), fields asked for once, twice, or not at all between calls; mean_u and tau from the same state."""
+    nx, ny = 132, 99
+    o = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision=coll, dtype=dtype, turb=turb)
+    with CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, kernel="tb") as s:
+        for n in range(1, 15):
+            o.step(n); s.step(n)
+            if n % 3 == 0:
+                continue                                   # no read between these calls
+            same(s, o, f"after a call of {n} steps")
+            if n % 2:
+                same(s, o, "asked twice")
+            m = s.mean_u()
+            assert abs(m - float(np.mean(o.u.astype(np.float64)))) < 1e-6 * 0.08
+        tau = s.get_tau()
+        if turb == 0:
+            assert np.all(tau == dtype(1.0) / dtype(s.relax["omega"]))
+        else:
+            assert tau.min() >= (1.0 / s.relax["omega"]) * (1 - 1e-6) and tau.max() > tau.min()
 
 
 def test_seeded_random_configurations_against_oracle():
@@ -496,11 +513,74 @@ def test_minimum_sizes_and_empty_calls(sem, coll):
     assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho)
 
 
-def test_maximum_size_16384_fp32():
-    """Edge case 'maximum sizes': 16384 x 16384 fp32 = 268 M cells, element offsets beyond 2^31 in the [y][k][x] layout
-    (9.7 GB per lattice).  A smooth non-trivial state advanced 9 steps as ONE lattice (raw first step, one four-step
-    launch, single steps) must equal the same state advanced as two slabs of 8192 rows with one step per launch."""
-    n, steps = 16384, 9
+def _threads():
+    return max(1, min(max_threads(), 16))
+
+
+@pytest.mark.parametrize("steps", [13, 20])
+def test_config_c3_4096_fp32_against_oracle(steps):
+    """BASELINE.json configs[2] at full size -- 4096 x 4096, Re = 1000, fp32, MRT, the lattice bench.py times -- against the C
+    oracle: the default kernels (several steps per launch) in the reference's operation order bit for bit; arith = fast (what
+    bench.py's headline runs) within 2e-5 of it.  20 steps = the driver's bench shape (raw step + multi-step units)."""
+    n = 4096
+    set_threads(_threads())
+    try:
+        o = CavityOracleC(n, n, 1000.0, semantics="mrt_gpu", collision="MRT", dtype=np.float32).step(steps)
+    finally:
+        set_threads(1)
+    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as s:
+        assert s.next_unit(100) >= 4
+        s.step(steps)
+        same(s, o, f"C3 strict, {steps} steps")
+    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, arith="fast") as f:
+        f.step(steps)
+        u, rho, fin = f.get_fields(want_fin=True)
+    assert np.abs(fin - o.fin).max() / np.abs(o.fin).max() < 2e-5
+    assert np.abs(u - o.u).max() / 0.08 < 2e-4 and np.abs(rho - o.rho).max() < 2e-5
+
+
+def test_config_c4_8192_fp64_re3200_slabs_and_oracle():
+    """BASELINE.json configs[3]: 8192 x 8192, Re = 3200, fp64, MRT, y-slabs for 8 GPUs.  On one device: the undivided lattice
+    (default multi-step kernels) == the C oracle after 10 steps, == the one-step vector kernel, == 8 slabs of 8192 x 1024
+    driven through the multi-step launch units with deep halos (what each of the 8 ranks runs), all bit for bit."""
+    n, steps, nslabs = 8192, 10, 8
+    set_threads(_threads())
+    try:
+        o = CavityOracleC(n, n, 3200.0, semantics="mrt_gpu", collision="MRT", dtype=np.float64).step(steps)
+    finally:
+        set_threads(1)
+    with CavitySolver(n, n, 3200.0, RT="MRT", dtype=np.float64) as one:
+        assert abs(one.relax["omega"] - 0.8973438621679827) < 1e-15         # SURVEY 8(d), C4
+        one.step(steps)
+        same(one, o, "C4 undivided")
+    u = np.zeros_like(o.u); rho = np.zeros_like(o.rho); fin = np.zeros_like(o.fin)
+    with CavitySolver(n, n, 3200.0, RT="MRT", dtype=np.float64, kernel="vec") as v:
+        v.step(steps)
+        v.get_fields(u=u, rho=rho, fin=fin)
+    assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho), "vec"
+    for arith in ("strict", "fast"):     # fast: five steps per launch on the slabs (strict fp64 MRT: three, last step single)
+        parts = partition_rows(n, nslabs)
+        slabs = [CavitySolver(n, n, 3200.0, RT="MRT", dtype=np.float64, rows=r, min_rows=n // nslabs, arith=arith) for r in parts]
+        assert slabs[3].next_unit(100) >= 3
+        LocalSlabs(slabs).step(steps)
+        u[:] = 0; rho[:] = 0; fin[:] = 0
+        for sl in slabs:
+            sl.get_fields(u=u, rho=rho, fin=fin)
+            sl.close()
+        if arith == "strict":
+            assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho), "8 slabs"
+        else:
+            assert np.abs(fin - o.fin).max() / np.abs(o.fin).max() < 1e-9 and np.abs(u - o.u).max() / 0.08 < 1e-9
+
+
+def test_config_c5_16384_fp32_re5000_slabs():
+    """BASELINE.json configs[4] (and the edge case 'maximum sizes'): 16384 x 16384, Re = 5000, fp32 = 268 M cells, element
+    offsets beyond 2^31 in the [y][k][x] layout (9.7 GB per lattice), cut into 8 slabs of 16384 x 2048 -- the per-GPU share of
+    the weak-scaling series, all 8 resident on the one device.  A smooth non-trivial state advanced 12 steps as ONE lattice
+    (arith = fast as benched: raw step, five-step launches, single step) must equal, bit for bit, the same state advanced by
+    the 8 slabs through the multi-step launch units with deep halos; the first 3 steps also against the C oracle's
+    reference-order arithmetic within the fast form's tolerance."""
+    n, steps, nslabs = 16384, 12, 8
     x = np.arange(n, dtype=np.float32)
     base = (1.0 + 1e-3 * np.sin(0.01 * x)[:, None] * np.cos(0.013 * x)[None, :]).astype(np.float32)
     t = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float32)
@@ -508,40 +588,54 @@ def test_maximum_size_16384_fp32():
     for k in range(9):
         np.multiply(base, t[k] * np.float32(1.0 + 1e-4 * k), out=fin0[k])
     del base
-    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as one:
+    with CavitySolver(n, n, 5000.0, RT="MRT", dtype=np.float32, arith="fast") as one:
+        assert abs(one.relax["omega"] - 0.7773438471679809) < 1e-15         # omega from the global height
         one.set_state(fin0)
         one.step(steps)
         u1, r1, f1 = one.get_fields(want_fin=True)
     assert np.isfinite(f1[:, ::97, ::89]).all() and abs(float(r1[::64, ::64].mean()) - 1.0) < 1e-2
-    slabs = [CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, rows=r, kernel="vec") for r in partition_rows(n, 2)]
-    for s in slabs:
-        s.set_state(fin0)
-    del fin0
+    slabs = [CavitySolver(n, n, 5000.0, RT="MRT", dtype=np.float32, arith="fast", rows=r, min_rows=n // nslabs) for r in partition_rows(n, nslabs)]
+    assert slabs[0].ny_local == 2048 and slabs[1].next_unit(100) == 5
+    for sl in slabs:
+        sl.set_state(fin0)
     LocalSlabs(slabs).step(steps)
     u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
-    for s in slabs:
-        s.get_fields(u=u, rho=rho, fin=fin)
-        s.close()
-    assert np.array_equal(rho, r1) and np.array_equal(u, u1)
-    for k in range(9):
-        assert np.array_equal(fin[k], f1[k]), k
+    for sl in slabs:
+        sl.get_fields(u=u, rho=rho, fin=fin)
+        sl.close()
+    assert np.array_equal(fin, f1) and np.array_equal(u, u1) and np.array_equal(rho, r1)
+    del u, rho, fin, u1, r1, f1
+    # a 16384 x 2048 slab-sized strip of the same state against the oracle (3 steps, strict order; the fast form within 2e-5)
+    m = 2048
+    sub = np.ascontiguousarray(fin0[:, :, :m])
+    del fin0
+    set_threads(_threads())
+    try:
+        o = CavityOracleC(n, m, 5000.0, semantics="mrt_gpu", collision="MRT", dtype=np.float32, ny_global=n)
+        o.set_state(sub)
+        o.step(3)
+    finally:
+        set_threads(1)
+    with CavitySolver(n, m, 5000.0 * m / n, RT="MRT", dtype=np.float32) as s:
+        s.set_relaxation(0, **o.relax)                                      # omega of Re = 5000 at the GLOBAL height (MRT_GPU.py:63)
+        s.set_state(sub)
+        s.step(3)
+        same(s, o, "C5 strip, strict")
 
 
 @pytest.mark.parametrize("kernel", ["generic", "vec", "tb"])
 @pytest.mark.parametrize("turb", [0, 1])
-def test_fast_arithmetic_agrees_with_oracle_to_rounding(kernel, turb, monkeypatch):
+def test_fast_arithmetic_agrees_with_oracle_to_rounding(kernel, turb):
     """arith='fast': the MRT operator in factored form with fused multiply-adds -- algebraically the same operator, not the
     reference's operation order, so the comparison with the oracle is by tolerance: fp64 full field
     <= 1e-9 relative after 10 steps; fp32 <= 1e-4 relative to the fp64 oracle after 100 steps (and <= 2e-5 to the fp32 one).
     Every kernel variant and all steps-per-launch settings of the multi-step kernel."""
     nx, ny = 132, 99
-    for tbs in (("2", "3", "4", "5") if kernel == "tb" else ("",)):
-        if tbs:
-            monkeypatch.setenv("LBM_TB_STEPS", tbs)
+    for tbs in ((2, 3, 4, 5) if kernel == "tb" else (0,)):
         a64 = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision="MRT", dtype=np.float64, turb=turb)
         a32 = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision="MRT", dtype=np.float32, turb=turb)
-        with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=np.float64, turb=turb, kernel=kernel, arith="fast") as d, \
-                CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=np.float32, turb=turb, kernel=kernel, arith="fast") as f:
+        with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=np.float64, turb=turb, kernel=kernel, arith="fast", tuning=dict(tb_steps=tbs)) as d, \
+                CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=np.float32, turb=turb, kernel=kernel, arith="fast", tuning=dict(tb_steps=tbs)) as f:
             d.step(10); a64.step(10)
             u, rho, fin = d.get_fields(want_fin=True)
             assert not np.array_equal(fin, a64.fin)                           # it really is the other operation order
@@ -558,17 +652,15 @@ def test_fast_arithmetic_agrees_with_oracle_to_rounding(kernel, turb, monkeypatc
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_fast_arithmetic_is_the_same_in_every_kernel(dtype, monkeypatch):
+def test_fast_arithmetic_is_the_same_in_every_kernel(dtype):
     """The factored operator spells its fused multiply-adds out, so the one-cell-per-thread kernel, the vector kernel and
     the multi-step kernels (any steps per launch), slabs or not, all give the same bits -- as the strict form does."""
     nx, ny, steps = 132, 99, 37
     with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=dtype, kernel="generic", arith="fast") as g:
         g.step(steps)
         ref = g.get_fields(want_fin=True)
-    for kernel, tbs in (("vec", ""), ("tb", "2"), ("tb", "3"), ("tb", "4"), ("tb", "5")):
-        if tbs:
-            monkeypatch.setenv("LBM_TB_STEPS", tbs)
-        with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=dtype, kernel=kernel, arith="fast") as s:
+    for kernel, tbs in (("vec", 0), ("tb", 2), ("tb", 3), ("tb", 4), ("tb", 5)):
+        with CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=dtype, kernel=kernel, arith="fast", tuning=dict(tb_steps=tbs)) as s:
             s.step(steps)
             assert all(np.array_equal(x, y) for x, y in zip(ref, s.get_fields(want_fin=True))), (kernel, tbs)
     slabs = [CavitySolver(nx, ny, 1000.0, RT="MRT", dtype=dtype, arith="fast", rows=r) for r in partition_rows(ny, 3)]
@@ -582,7 +674,7 @@ def test_fast_arithmetic_is_the_same_in_every_kernel(dtype, monkeypatch):
 
 @pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
 @pytest.mark.parametrize("turb", [0, 1])
-def test_fast_arithmetic_srt_trt_and_closure(coll, turb, monkeypatch):
+def test_fast_arithmetic_srt_trt_and_closure(coll, turb):
     """arith='fast' beyond the MRT operator: u = j * rcp(rho) and the closure's divisions / square root use the hardware's
     reciprocal and square-root instructions (fp32: 1 ulp; fp64: v_rcp_f64 / v_rsq_f64 refined by Newton steps).  Tolerance
     against the oracle after 100 steps: fp32 2e-5 on the populations, 2e-4 on u / uLB; fp64 1e-9.  All kernel variants give
@@ -591,10 +683,8 @@ def test_fast_arithmetic_srt_trt_and_closure(coll, turb, monkeypatch):
     for dtype, tol_f, tol_u in ((np.float32, 2e-5, 2e-4), (np.float64, 1e-9, 1e-9)):
         o = CavityOracleC(nx, ny, 5000.0, semantics="mrt_gpu", collision=coll, dtype=dtype, turb=turb).step(steps)
         ref = None
-        for kernel, tbs in (("generic", ""), ("vec", ""), ("tb", "3"), ("tb", "5")):
-            if tbs:
-                monkeypatch.setenv("LBM_TB_STEPS", tbs)
-            with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel=kernel, arith="fast") as s:
+        for kernel, tbs in (("generic", 0), ("vec", 0), ("tb", 3), ("tb", 5)):
+            with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel=kernel, arith="fast", tuning=dict(tb_steps=tbs)) as s:
                 s.step(steps)
                 got = s.get_fields(want_fin=True)
             if ref is None:
@@ -603,7 +693,6 @@ def test_fast_arithmetic_srt_trt_and_closure(coll, turb, monkeypatch):
                 assert np.abs(got[0] - o.u).max() / 0.08 < tol_u
             else:
                 assert all(np.array_equal(x, y) for x, y in zip(ref, got)), (kernel, tbs, np.dtype(dtype).name)
-        monkeypatch.delenv("LBM_TB_STEPS")
 
 
 def test_fast_arithmetic_config_c1_centrelines():
@@ -726,66 +815,110 @@ def test_rccl_single_rank_communicator_is_transparent():
         assert all(np.array_equal(x, y) for x, y in zip(a.get_fields(want_fin=True), b.get_fields(want_fin=True)))
 
 
-@pytest.mark.parametrize("deep", ["1", "0"])
+@pytest.mark.parametrize("deep", [True, False])
 @pytest.mark.parametrize("kernel,layout", [("auto", "rows"), ("tb", "rows"), ("tb", "planes")])
 @pytest.mark.parametrize("dtype,coll,turb,arith", [(np.float32, "MRT", 0, "strict"), (np.float64, "SRT", 1, "strict"),
                                                    (np.float32, "MRT", 0, "fast"), (np.float32, "TRT", 1, "strict")])
-def test_rccl_exchange_path_in_loopback(dtype, coll, turb, arith, kernel, layout, deep, monkeypatch):
+def test_rccl_exchange_path_in_loopback(dtype, coll, turb, arith, kernel, layout, deep):
     """lbm_step's in-library exchange (edge/interior split, comm stream, events, ncclSend/ncclRecv straight from
     lattice rows into ghost rows) on ONE GPU: a middle slab exchanges with itself (periodic in y).  Expected
     result: the same slab stepped with the externally driven API and the same wrap done through host buffers.
-    kernel='tb': multi-step launches between slabs -- one deep exchange per launch (LBM_DEEP_HALO=1, the default: the frame
-    passes recompute a shrinking band of the neighbour's rows) or one one-row exchange per pass (LBM_DEEP_HALO=0)."""
+    kernel='tb': multi-step launches between slabs -- one deep exchange per launch (the default: the frame
+    passes recompute a shrinking band of the neighbour's rows) or one one-row exchange per pass (tuning deep_halo=False).
+    u / rho are read after calls that end in a multi-step unit (recomputed from the unit's deep halo) and in a single step."""
     from latticeboltzmannsimulations_amd.slab import LOW, HIGH
-    monkeypatch.setenv("LBM_DEEP_HALO", deep)
-    nx, NY, rows, steps = 512, 300, (100, 96), 31
-    a = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel=kernel, layout=layout, arith=arith)
+    nx, NY, rows = 512, 300, (100, 96)
+    a = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel=kernel, layout=layout, arith=arith,
+                     tuning=dict(deep_halo=deep))
     b = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel="generic", layout=layout, arith=arith)
     a.comm_loopback()
-    a.step(steps - 8)
-    a.step(8)                      # a second call: starts with the halo of the first call's last (single) step
     up = np.empty(b.halo_elems(), dtype=dtype); down = np.empty(b.halo_elems(), dtype=dtype)
-    for _ in range(steps):
-        b.step_edges(); b.step_interior(); b.step_finish()
-        b.halo_export(LOW, up.ctypes.data); b.halo_export(HIGH, down.ctypes.data)
-        b.halo_import(HIGH, up.ctypes.data); b.halo_import(LOW, down.ctypes.data)
-    fa, fb = a.get_fields(want_fin=True), b.get_fields(want_fin=True)
-    assert all(np.array_equal(x, y) for x, y in zip(fa, fb))
+    for steps in (23, 8, 1, 10):   # several calls: each starts from the one-row halo the previous one left
+        a.step(steps)
+        for _ in range(steps):
+            b.step_edges(); b.step_interior(); b.step_finish()
+            b.halo_export(LOW, up.ctypes.data); b.halo_export(HIGH, down.ctypes.data)
+            b.halo_import(HIGH, up.ctypes.data); b.halo_import(LOW, down.ctypes.data)
+        fa, fb = a.get_fields(want_fin=True), b.get_fields(want_fin=True)
+        assert all(np.array_equal(x, y) for x, y in zip(fa, fb)), steps
     assert np.isfinite(fa[2][:, :, rows[0]:rows[0] + rows[1]]).all()
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("sides", ["1", "2"])
-@pytest.mark.parametrize("dtype,coll,turb,arith", [(np.float32, "MRT", 0, "fast"), (np.float64, "SRT", 0, "strict"),
-                                                   (np.float32, "MRT", 1, "strict")])
-def test_rccl_exchange_with_one_neighbour_only(dtype, coll, turb, arith, sides, monkeypatch):
-    """The first and the last rank have ONE neighbour.  On one GPU: a middle slab in loopback whose wrap is switched off on
-    one side (that side keeps reading its never-written ghost rows -- a synthetic but deterministic boundary), against the
-    externally driven exchange doing the same.  Per-pass exchange only: the deep halo recomputes the neighbour's rows, which
-    equals the exchanged rows only if the neighbour's rows evolve like their images -- true for a real neighbour and for the
-    two-sided wrap of test_rccl_exchange_path_in_loopback, not for a wrap whose far side is cut off."""
-    deep = "0"
-    from latticeboltzmannsimulations_amd.slab import LOW, HIGH
-    monkeypatch.setenv("LBM_DEEP_HALO", deep)
-    monkeypatch.setenv("LBM_DEBUG_LOOPBACK_SIDES", sides)
-    nx, NY, rows, steps = 256, 300, (100, 96), 23
-    a = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel="tb", arith=arith)
-    b = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel="generic", arith=arith)
-    a.comm_loopback()
-    a.step(steps)
-    buf = np.empty(b.halo_elems(), dtype=dtype)
-    for _ in range(steps):
-        b.step_edges(); b.step_interior(); b.step_finish()
-        if sides == "2":      # only the HIGH side has a neighbour: its ghost row receives what leaves through LOW
-            b.halo_export(LOW, buf.ctypes.data); b.halo_import(HIGH, buf.ctypes.data)
-        else:
-            b.halo_export(HIGH, buf.ctypes.data); b.halo_import(LOW, buf.ctypes.data)
-    fa, fb = a.get_fields(want_fin=True), b.get_fields(want_fin=True)
-    # (SRT + closure is left out: next to the cut-off side, which pulls zeros, it produces NaNs, and a NaN in a wall cell's
-    # parked -- otherwise dead -- slot differs between the two paths' buffers)
-    assert np.isfinite(fa[2][:, :, rows[0]:rows[0] + rows[1]]).all()
-    assert all(np.array_equal(x, y) for x, y in zip(fa, fb))
-    a.close(); b.close()
+def test_slab_without_a_communicator_is_refused():
+    """lbm_step / lbm_time_steps on a slab with no transport attached would read ghost rows nobody fills: LBM_ERR_STATE."""
+    with CavitySolver(256, 128, 100.0, rows=(0, 64)) as s:
+        with pytest.raises(RuntimeError, match="without a communicator"):
+            s.step(3)
+        with pytest.raises(RuntimeError, match="without a communicator"):
+            s.time_steps(3)
+        s.step_edges(); s.step_interior(); s.step_finish()      # the externally driven calls are what such a slab takes
+        assert s.steps_done == 1
+
+
+SLAB_CASES = [(np.float32, "MRT", 0, "strict"), (np.float32, "MRT", 0, "fast"), (np.float64, "SRT", 1, "strict"),
+              (np.float64, "MRT", 0, "strict"), (np.float64, "MRT", 0, "fast")]
+
+
+@pytest.mark.parametrize("nslabs", [2, 3, 8])
+@pytest.mark.parametrize("dtype,coll,turb,arith", SLAB_CASES)
+def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, arith, nslabs):
+    """What every rank of a decomposition runs between its RCCL calls -- first slab (lid, one neighbour below), middle slabs,
+    last slab (bottom wall): launch units of S steps, each preceded by the exchange of the S complete rows next to every
+    interface (lbm_halo_export_rows -> lbm_halo_import_rows) and run by lbm_step_unit = lbm_step's own multi-step launch
+    sequence (frame passes that recompute a shrinking band of the neighbour's rows + tile kernel, two streams).  Uneven slab
+    heights, several calls whose lengths leave every remainder, fields read after every call (one-step lag recomputed from
+    the deep halo on slabs).  Expected: the undivided lattice, bit for bit (and the C oracle for strict arithmetic)."""
+    nx, ny = 512, 75 * 8 + 5
+    calls = (1, 13, 5, 9, 4, 16, 3)
+    parts = partition_rows(ny, nslabs)
+    mr = min(n for _, n in parts)
+    o = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision=coll, dtype=dtype, turb=turb) if arith == "strict" else None
+    one = CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel="vec")
+    slabs = [CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel="tb", rows=r, min_rows=mr) for r in parts]
+    assert slabs[0].next_unit(1) == 1                                       # raw lattice: a single step first
+    drv = LocalSlabs(slabs)
+    units = set()
+    for n in calls:
+        units.add(slabs[-1].next_unit(n))
+        drv.step(n); one.step(n)
+        ref = one.get_fields(want_fin=True)
+        u = np.zeros_like(ref[0]); rho = np.zeros_like(ref[1]); fin = np.zeros_like(ref[2])
+        for sl in slabs:
+            sl.get_fields(u=u, rho=rho, fin=fin)
+        assert np.array_equal(fin, ref[2]) and np.array_equal(u, ref[0]) and np.array_equal(rho, ref[1]), n
+        if o is not None:
+            o.step(n)
+            assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho), n
+    assert max(units) >= 3, units                                           # the multi-step path really ran
+    means = [sl.mean_u() * sl.ny_local for sl in slabs]
+    assert abs(sum(means) / ny - one.mean_u()) < 1e-12
+    for sl in slabs:
+        sl.close()
+    one.close()
+
+
+def test_slabs_derive_one_plan_from_the_smallest_slab():
+    """Two neighbours on opposite sides of a size threshold (768 x 1535 rows cut in two: 768 and 767 rows) must still run the
+    same protocol: with min_rows = the smallest slab both report the same launch units; without it they may not, and the
+    driver refuses to continue instead of posting mismatched exchanges."""
+    nx, ny = 768, 1535
+    parts = partition_rows(ny, 2)
+    mr = min(n for _, n in parts)
+    good = [CavitySolver(nx, ny, 1000.0, dtype=np.float32, rows=r, min_rows=mr) for r in parts]
+    for left in (1, 5, 9, 40):
+        assert good[0].next_unit(left) == good[1].next_unit(left)
+    LocalSlabs(good).step(12)
+    with CavitySolver(nx, ny, 1000.0, dtype=np.float32, kernel="vec") as one:
+        one.step(12)
+        ref = one.get_fields(want_fin=True)
+    u = np.zeros_like(ref[0]); rho = np.zeros_like(ref[1]); fin = np.zeros_like(ref[2])
+    for sl in good:
+        sl.get_fields(u=u, rho=rho, fin=fin)
+        sl.close()
+    assert np.array_equal(fin, ref[2]) and np.array_equal(u, ref[0]) and np.array_equal(rho, ref[1])
+    with pytest.raises(RuntimeError, match="ny_local_min"):
+        CavitySolver(nx, ny, 1000.0, dtype=np.float32, rows=parts[1], min_rows=parts[1][1] + 1)
 
 
 def test_timing_and_bandwidth_probes():

@@ -1,5 +1,5 @@
 """Multi-slab host logic on CPU: (1) several slabs in one process, (2) world_size-2 and -3
-torch.distributed runs over gloo.  The compute is the stand-in stepper (tests/slab_standin.py);
+torch.distributed runs over gloo, incl. world 8 with multi-step launch units.  The compute is the stand-in stepper (tests/slab_standin.py);
 the code under test is the product's slab.py (partition, neighbours, side/plane conventions,
 driver ordering, P2P transport).  The result must be bit-identical to the undivided oracle."""
 import os
@@ -32,34 +32,68 @@ def test_local_slabs_equal_single_domain(sem, coll, nslabs):
     assert np.array_equal(fin, ref.fin) and np.array_equal(u, ref.u) and np.array_equal(rho, ref.rho)
 
 
+@pytest.mark.parametrize("unit", [3, 5])
+@pytest.mark.parametrize("nslabs", [2, 3, 8])
+def test_local_slabs_multi_step_units_equal_single_domain(nslabs, unit):
+    """The launch-unit schedule with deep halos (S complete rows per side, then S steps without communication) for first,
+    middle and last slabs, uneven heights, several step() calls of lengths that leave every kind of remainder."""
+    nx, ny = 18, 67
+    ref = on.CavityOracle(nx, ny, 100.0, semantics="mrt_gpu", collision="MRT")
+    slabs = [SlabStandIn(nx, ny, 100.0, r, semantics="mrt_gpu", collision="MRT", unit=unit) for r in partition_rows(ny, nslabs)]
+    drv = LocalSlabs(slabs)
+    for n in (1, unit, 2 * unit + 1, 4, unit + 2, 3):
+        drv.step(n)
+        ref.step(n)
+        fin = np.concatenate([s.fin for s in slabs], axis=2)
+        u = np.concatenate([s.u for s in slabs], axis=2)
+        rho = np.concatenate([s.rho for s in slabs], axis=1)
+        assert np.array_equal(fin, ref.fin) and np.array_equal(u, ref.u) and np.array_equal(rho, ref.rho), n
+
+
+def test_slabs_that_disagree_on_the_unit_are_refused():
+    nx, ny = 16, 40
+    parts = partition_rows(ny, 2)
+    slabs = [SlabStandIn(nx, ny, 100.0, parts[0], semantics="mrt_gpu", collision="MRT", unit=5),
+             SlabStandIn(nx, ny, 100.0, parts[1], semantics="mrt_gpu", collision="MRT", unit=3)]
+    drv = LocalSlabs(slabs)
+    drv.step(1)
+    with pytest.raises(RuntimeError, match="disagree"):
+        drv.step(10)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nx, ny, steps, sem, coll, q):
+def _worker(rank, world, port, nx, ny, steps, sem, coll, q, unit=1):
     import torch.distributed as dist
     from latticeboltzmannsimulations_amd.slab import HaloDriver
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         rows = partition_rows(ny, world)[rank]
-        st = SlabStandIn(nx, ny, 100.0, rows, semantics=sem, collision=coll)
-        HaloDriver(st, rank, world, device="cpu").step(steps)
+        st = SlabStandIn(nx, ny, 100.0, rows, semantics=sem, collision=coll, unit=unit)
+        drv = HaloDriver(st, rank, world, device="cpu")
+        for n in (steps if isinstance(steps, (list, tuple)) else [steps]):
+            drv.step(n)
         q.put((rank, rows, st.fin, st.u, st.rho))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,sem,coll", [(2, "mrt_gpu", "MRT"), (2, "mrt_py", "SRT"), (3, "mrt_gpu", "SRT")])
-def test_gloo_halo_driver_equals_single_domain(world, sem, coll):
+@pytest.mark.parametrize("world,sem,coll,unit,ny,steps", [(2, "mrt_gpu", "MRT", 1, 19, 10), (2, "mrt_py", "SRT", 1, 19, 10), (3, "mrt_gpu", "SRT", 1, 19, 10),
+                                                           # multi-step launch units with deep halos, several calls (world 2, 3, 8)
+                                                           (2, "mrt_gpu", "MRT", 5, 23, [1, 12, 4]), (3, "mrt_gpu", "MRT", 4, 31, [9, 7]),
+                                                           (8, "mrt_gpu", "MRT", 5, 83, [1, 5, 8])])
+def test_gloo_halo_driver_equals_single_domain(world, sem, coll, unit, ny, steps):
     import torch.multiprocessing as mp
-    nx, ny, steps = 16, 19, 10
+    nx = 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ny, steps, sem, coll, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ny, steps, sem, coll, q, unit)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in range(world)]
@@ -67,7 +101,7 @@ def test_gloo_halo_driver_equals_single_domain(world, sem, coll):
         p.join(timeout=60)
         assert p.exitcode == 0
     got.sort(key=lambda t: t[0])
-    ref = on.CavityOracle(nx, ny, 100.0, semantics=sem, collision=coll).step(steps)
+    ref = on.CavityOracle(nx, ny, 100.0, semantics=sem, collision=coll).step(sum(steps) if isinstance(steps, list) else steps)
     fin = np.concatenate([g[2] for g in got], axis=2)
     u = np.concatenate([g[3] for g in got], axis=2)
     rho = np.concatenate([g[4] for g in got], axis=1)
