@@ -245,15 +245,16 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0
 // All S frame passes lat[from] -> lat[to] in one launch (k_frame_multi); lo / hi: the slab has a neighbour below row 0 / above
 // row ny - 1 whose rows lie in the ghost rows (deep halo).
 // Do the LDS windows of the fused frame passes fit (two buffers of the largest pass-1 rectangle plus its ring)?
-bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows) {
+bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows, int extra = 0) {
     if (!c->frame_lds) return false;
     const int F = c->tb_f, L = c->frame_seg, m = S - 1, np = c->p.turb ? Q + 2 : Q;
-    const long long row_strip = (long long)(L + 2 * m + 2) * (F + m + (deep_rows ? m : 0) + 2);
+    const long long row_strip = (long long)(L + 2 * m + 2) * (F + m + (deep_rows ? m + extra : 0) + 2);
     const long long col_strip = (long long)(F + m + 2) * (L + 2 * m + 2);
     return 2 * np * std::max(row_strip, col_strip) * c->es <= FRAME_LDS_BYTES;
 }
 
-int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool lo, bool hi) {
+// extra: rows of the neighbours' side that the row strips own on top of the slab's (see frame_passes)
+int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool lo, bool hi, int extra = 0) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
@@ -262,7 +263,8 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
         for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
         const int F = c->tb_f, L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
         hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
-                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 : 0, hi ? 1 : 0, L, frame_lds_fits(c, S, lo || hi) ? 1 : 0);
+                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 + extra : 0, hi ? 1 + extra : 0, L,
+                           frame_lds_fits(c, S, lo || hi, extra) ? 1 : 0);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -602,13 +604,15 @@ int prev_lattice(lbm_ctx* c, int* which) {
             rc = launch_deep(c, from, LAT_LAG, c->s_compute, k, true);
         } else {
             const bool lo = has_neighbour(c, LBM_SIDE_LOW), hi = has_neighbour(c, LBM_SIDE_HIGH);
-            if (c->frame_fused) rc = launch_frame_multi(c, from, LAT_LAG, k, c->s_compute, lo, hi);
+            // one row more than a launch unit computes: the field export pulls the slab's first / last row from the first ghost
+            // rows of this lattice (the unit received S = k + 1 rows per side: enough)
+            if (c->frame_fused) rc = launch_frame_multi(c, from, LAT_LAG, k, c->s_compute, lo, hi, 1);
             else {
                 rc = LBM_OK;
                 int f = from;
                 for (int i = 1; i <= k && rc == LBM_OK; ++i) {
                     const int to = i == k ? LAT_LAG : 2 + ((i - 1) & 1);
-                    rc = launch_frame(c, f, to, c->tb_f + k - i, c->s_compute, lo ? k - i : 0, hi ? k - i : 0);
+                    rc = launch_frame(c, f, to, c->tb_f + k - i, c->s_compute, lo ? k - i + 1 : 0, hi ? k - i + 1 : 0);
                     f = to;
                 }
             }

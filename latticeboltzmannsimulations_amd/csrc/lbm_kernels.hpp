@@ -114,11 +114,16 @@ constexpr int FRAME_LDS_BYTES = 48 * 1024;
 template <typename R, int COLL, int SEM, bool TURB, int NT>
 __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long boff, const Geo& geo, const Relax<R>& w, int F, int S,
                                              int nsegx, int nsegy, int lo, int hi, int b, int FR_L, R* lds) {
+    // lo / hi: 0 = no neighbour on that side; e + 1 = a neighbour whose rows lie in the ghost rows, and the row strips own e of
+    // them (e = 0: a launch unit; e = 1: the recomputation of the lattice of the step before the last, whose first ghost rows
+    // the field export pulls from)
+    const int elo = lo > 0 ? lo - 1 : 0, ehi = hi > 0 ? hi - 1 : 0;
     int x0, x1, y0, y1;   // owned rectangle [x0, x1) x [y0, y1)
     if (b < 2 * nsegx) {
         const int seg = b % nsegx;
         x0 = seg * FR_L; x1 = min(geo.nx, x0 + FR_L);
-        y0 = b < nsegx ? 0 : geo.ny - F; y1 = y0 + F;
+        if (b < nsegx) { y0 = -elo; y1 = F; }
+        else { y0 = geo.ny - F; y1 = geo.ny + ehi; }
     } else {
         b -= 2 * nsegx;
         const int seg = b % nsegy;
@@ -133,7 +138,7 @@ __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long b
         constexpr int NP = TURB ? Q + 2 : Q;
         const int m1 = S - 1;
         const int xa1 = max(0, x0 - m1), xb1 = min(geo.nx, x1 + m1);
-        const int ya1 = max(lo ? -m1 : 0, y0 - m1), yb1 = min(geo.ny + (hi ? m1 : 0), y1 + m1);
+        const int ya1 = max(lo ? -(m1 + elo) : 0, y0 - m1), yb1 = min(geo.ny + (hi ? m1 + ehi : 0), y1 + m1);
         Window win;
         win.x0 = xa1 - 1; win.y0 = ya1 - 1; win.pitch = xb1 - xa1 + 2; win.plane = win.pitch * (yb1 - ya1 + 2);
         R* const buf0 = lds;
@@ -143,7 +148,7 @@ __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long b
         for (int i = 1; i <= S; ++i) {
             const int m = S - i;
             const int xa = max(0, x0 - m), xb = min(geo.nx, x1 + m);
-            const int ya = max(lo ? -m : 0, y0 - m), yb = min(geo.ny + (hi ? m : 0), y1 + m);
+            const int ya = max(lo ? -(m + elo) : 0, y0 - m), yb = min(geo.ny + (hi ? m + ehi : 0), y1 + m);
             const int wx = xb - xa, n = wx * (yb - ya);
             R* const wr = (i & 1) ? buf0 : buf1;
             const R* const rd = (i & 1) ? buf1 : buf0;
@@ -166,7 +171,7 @@ __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long b
     for (int i = 1; i <= S; ++i) {
         const int m = S - i;
         const int xa = max(0, x0 - m), xb = min(geo.nx, x1 + m);
-        const int ya = max(lo ? -m : 0, y0 - m), yb = min(geo.ny + (hi ? m : 0), y1 + m);
+        const int ya = max(lo ? -(m + elo) : 0, y0 - m), yb = min(geo.ny + (hi ? m + ehi : 0), y1 + m);
         const int wx = xb - xa, n = wx * (yb - ya);
         const R* src = (i == 1 ? fp.src : pass_ptr(fp, i - 2)) + boff;
         R* dst = pass_ptr(fp, i - 1) + boff;

@@ -529,8 +529,8 @@ def test_config_c3_4096_fp32_against_oracle(steps):
     finally:
         set_threads(1)
     with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as s:
-        assert s.next_unit(100) >= 4
         s.step(steps)
+        assert s.next_unit(100) >= 4                                         # (several steps per launch is what ran)
         same(s, o, f"C3 strict, {steps} steps")
     with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32, arith="fast") as f:
         f.step(steps)
@@ -561,8 +561,8 @@ def test_config_c4_8192_fp64_re3200_slabs_and_oracle():
     for arith in ("strict", "fast"):     # fast: five steps per launch on the slabs (strict fp64 MRT: three, last step single)
         parts = partition_rows(n, nslabs)
         slabs = [CavitySolver(n, n, 3200.0, RT="MRT", dtype=np.float64, rows=r, min_rows=n // nslabs, arith=arith) for r in parts]
-        assert slabs[3].next_unit(100) >= 3
         LocalSlabs(slabs).step(steps)
+        assert slabs[3].next_unit(100) >= 3
         u[:] = 0; rho[:] = 0; fin[:] = 0
         for sl in slabs:
             sl.get_fields(u=u, rho=rho, fin=fin)
@@ -595,10 +595,10 @@ def test_config_c5_16384_fp32_re5000_slabs():
         u1, r1, f1 = one.get_fields(want_fin=True)
     assert np.isfinite(f1[:, ::97, ::89]).all() and abs(float(r1[::64, ::64].mean()) - 1.0) < 1e-2
     slabs = [CavitySolver(n, n, 5000.0, RT="MRT", dtype=np.float32, arith="fast", rows=r, min_rows=n // nslabs) for r in partition_rows(n, nslabs)]
-    assert slabs[0].ny_local == 2048 and slabs[1].next_unit(100) == 5
     for sl in slabs:
         sl.set_state(fin0)
     LocalSlabs(slabs).step(steps)
+    assert slabs[0].ny_local == 2048 and slabs[1].next_unit(100) == 5
     u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
     for sl in slabs:
         sl.get_fields(u=u, rho=rho, fin=fin)
