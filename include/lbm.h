@@ -37,12 +37,14 @@ enum { LBM_F32 = 0, LBM_F64 = 1 };                      /* storage and arithmeti
 enum { LBM_SRT = 0, LBM_TRT = 1, LBM_MRT = 2 };         /* RT = 'SRT' | 'TRT' | 'MRT'  (MRT_GPU.py:48) */
 enum { LBM_SEM_MRT_PY = 0, LBM_SEM_MRT_GPU = 1 };       /* streaming windows + wall rules of MRT.py:404-453
                                                            or of MRT_GPU.py:412,674-692 */
-enum { LBM_KERNEL_AUTO = 0,      /* fastest applicable: TB (lattices from 64 x 64 cells), else VEC, else GENERIC */
+enum { LBM_KERNEL_AUTO = 0,      /* fastest applicable: STREAM (large lattices), TB (lattices from 64 x 64 cells), else VEC, else GENERIC */
        LBM_KERNEL_GENERIC = 1,   /* one step per launch, one thread per cell (all semantics) */
        LBM_KERNEL_VEC = 2,       /* one step per launch, 16 B per access (MRT_GPU semantics) */
        LBM_KERNEL_TB = 3,        /* several (3 .. 5) time steps per launch: tiles through LDS + the wall frame */
-       LBM_KERNEL_PUSH = 4 };    /* the reference's own scheme for A/B: collide-and-push into a persistent second array, then a
+       LBM_KERNEL_PUSH = 4,      /* the reference's own scheme for A/B: collide-and-push into a persistent second array, then a
                                     wall-rule + copy kernel (funRT + funBC, MRT_GPU.py:339-698); one whole lattice, no closure */
+       LBM_KERNEL_STREAM = 5 };  /* up to 8 time steps per launch, streamed down column strips (rows held in registers, neighbour rows
+                                    through LDS): what AUTO picks for large lone lattices; otherwise as TB */
 enum { LBM_LAYOUT_AUTO = 0, LBM_LAYOUT_PLANES = 1, LBM_LAYOUT_ROWS = 2 }; /* device arrays: [k][y][x] or [y][k][x] */
 enum { LBM_ARITH_STRICT = 0, LBM_ARITH_FAST = 1 };
 enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour towards smaller / larger y */
@@ -88,7 +90,7 @@ typedef struct lbm_params {
     int32_t ny_local_min; /* slabs: the smallest ny_local of ALL ranks (0: = ny_local).  The launch plan (steps per launch, frame
                             width, deep halo) is derived from it, so that every rank of a decomposition runs the same exchange
                             protocol whatever its own share of the rows; lbm_comm_init() cross-checks the plan with both neighbours. */
-    int32_t tb_steps;    /* 0: measured default.  2 .. 5: time steps per launch of the multi-step path (A/B, tests) */
+    int32_t tb_steps;    /* 0: measured default.  2 .. 5 (STREAM: 2 .. 8): time steps per launch of the multi-step path (A/B, tests) */
     int32_t frame_seg;   /* 0: default by lattice size.  >= 8: cells of the wall frame per workgroup of the fused frame passes */
     int32_t flags;       /* LBM_FLAG_* bits, 0 = defaults */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */

@@ -19,7 +19,7 @@ LINK_FLAGS = ["-ldl"]   # RCCL is bound lazily with dlopen inside the library
 LBM_F32, LBM_F64 = 0, 1
 LBM_SRT, LBM_TRT, LBM_MRT = 0, 1, 2
 LBM_SEM_MRT_PY, LBM_SEM_MRT_GPU = 0, 1
-LBM_KERNEL_AUTO, LBM_KERNEL_GENERIC, LBM_KERNEL_VEC, LBM_KERNEL_TB, LBM_KERNEL_PUSH = 0, 1, 2, 3, 4
+LBM_KERNEL_AUTO, LBM_KERNEL_GENERIC, LBM_KERNEL_VEC, LBM_KERNEL_TB, LBM_KERNEL_PUSH, LBM_KERNEL_STREAM = 0, 1, 2, 3, 4, 5
 LBM_LAYOUT_AUTO, LBM_LAYOUT_PLANES, LBM_LAYOUT_ROWS = 0, 1, 2
 LBM_SIDE_LOW, LBM_SIDE_HIGH = 0, 1
 LBM_ARITH_STRICT, LBM_ARITH_FAST = 0, 1

@@ -11,8 +11,8 @@ namespace lbm {
 
 constexpr int Q = 9;
 constexpr int GH = 4;  // ghost/pad columns on each side of a row (keeps x = 0 16-byte aligned)
-constexpr int GHY = 6; // ghost rows above and below a lattice: row -1 / ny is the one-row halo of a slab (and holds parked wall data);
-                       // rows -5 .. -1 / ny .. ny+4 receive the neighbour's rows for the multi-step launches (deep halo)
+constexpr int GHY = 10; // ghost rows above and below a lattice: row -1 / ny is the one-row halo of a slab (and holds parked wall data);
+                        // rows -S .. -1 / ny .. ny+S-1 receive the neighbour's rows for the multi-step launches (deep halo, S <= 8)
 
 // a1: lattice vectors, MRT.py:138-140 (k: 0 rest, 1 E, 2 N, 3 W, 4 S, 5 NE, 6 NW, 7 SW, 8 SE).
 // A population moves from (x, y) to (x + cx, y - cy): y = 0 is the lid (MRT_GPU.py:412-413).

@@ -20,6 +20,7 @@
 // kernels
 // ------------------------------------------------------------------------------------
 #include "lbm_tiles_inst.hpp"   // extern template declarations of k_stepS_deep unless LBM_SINGLE_TU
+#include "lbm_stream.hpp"       // ... and of k_stream (lbm_stream_f32.hip / lbm_stream_f64.hip)
 
 // (not a template: defined in this translation unit only)
 __global__ __launch_bounds__(BLK) void k_copy16(const uint4* __restrict__ a, uint4* __restrict__ b, size_t n) {
@@ -40,16 +41,16 @@ __global__ __launch_bounds__(BLK) void k_reduce_final(const double* __restrict__
 // ------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------
-constexpr int LAT_LAG = 6;    // lat[LAT_LAG]: the lattice of the step before the last, recomputed on demand (lazy one-step lag)
-constexpr int NLAT = 7;
+constexpr int LAT_LAG = 9;    // lat[LAT_LAG]: the lattice of the step before the last, recomputed on demand (lazy one-step lag)
+constexpr int NLAT = 10;
 
 struct lbm_ctx {
     lbm_params p{};
     int es = 0;  // element size
     Geo geo{};
-    void* lat[NLAT] = {};       // [0], [1]: the two lattices; [2] .. [5]: frame scratch of the multi-step; [LAT_LAG]: see above
+    void* lat[NLAT] = {};       // [0], [1]: the two lattices; [2] .. [8]: frame scratch of the multi-step; [LAT_LAG]: see above
     size_t lat_bytes = 0;
-    int raw[NLAT] = {1, 1, 0, 0, 0, 0, 0};
+    int raw[NLAT] = {1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
     int cur = 0;  // lat[cur] is the source of the next step
     long long nsteps = 0;
     // One-step lag of u / rho: the fields of the last iteration are moments of the state it started from.
@@ -76,7 +77,9 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
     bool use_tb = false;        // several steps per launch (temporal blocking)
-    int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel)
+    bool stream = false;        // ... by the strip-streaming kernel (lbm_stream.hpp: large lone lattices, up to 8 steps per launch)
+    int ncu = 256;              // compute units of the device (the streaming kernel runs one workgroup per CU)
+    int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel), up to eight (streaming kernel)
     int tb_f = TB_F;            // frame width
     int batch = 1;              // independent lattices per buffer (lbm_params.batch)
     long long bstride = 0;      // elements from one lattice of the batch to the next
@@ -245,12 +248,12 @@ int launch_frame(lbm_ctx* c, int from, int to, int W, hipStream_t s, int elo = 0
 // All S frame passes lat[from] -> lat[to] in one launch (k_frame_multi); lo / hi: the slab has a neighbour below row 0 / above
 // row ny - 1 whose rows lie in the ghost rows (deep halo).
 // Do the LDS windows of the fused frame passes fit (two buffers of the largest pass-1 rectangle plus its ring)?
-bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows, int extra = 0) {
+bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows, int extra = 0, long long budget = FRAME_LDS_BYTES) {
     if (!c->frame_lds) return false;
     const int F = c->tb_f, L = c->frame_seg, m = S - 1, np = c->p.turb ? Q + 2 : Q;
     const long long row_strip = (long long)(L + 2 * m + 2) * (F + m + (deep_rows ? m + extra : 0) + 2);
     const long long col_strip = (long long)(F + m + 2) * (L + 2 * m + 2);
-    return 2 * np * std::max(row_strip, col_strip) * c->es <= FRAME_LDS_BYTES;
+    return 2 * np * std::max(row_strip, col_strip) * c->es <= budget;
 }
 
 // extra: rows of the neighbours' side that the row strips own on top of the slab's (see frame_passes)
@@ -260,7 +263,7 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
         using R = typename VT::R;
         FramePtrs<R> fp;
         fp.src = (const R*)c->lat[from];
-        for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+        for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
         const int F = c->tb_f, L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
         hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
                            relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 + extra : 0, hi ? 1 + extra : 0, L,
@@ -271,7 +274,46 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
 }
 
 // `steps` steps on the deep interior, lat[from] -> lat[to] (c->tb_steps, or fewer for the last launch of a call).
+// Segments of the streaming kernel: strips of 64 V - 2 R useful columns, each cut into nsegy segments of H rows; one
+// workgroup per segment and ONE workgroup per CU, so the plan minimises rounds x iterations per segment (a segment of H rows
+// takes H + 2 (S - 1) rows through the pipeline plus its fill).
+struct StreamPlan { int nstrips, nsegy, H; };
+StreamPlan plan_stream(const lbm_ctx* c, int S) {
+    const int V = 16 / c->es, Rr = stream_rim(S, V), TXu = 64 * V - 2 * Rr, F = c->tb_f;
+    const int cols = c->geo.nx - 2 * F, rows = c->geo.ny - 2 * F;
+    StreamPlan best{(cols + TXu - 1) / TXu, 1, rows};
+    long long best_cost = -1;
+    for (int n = 1; n <= 256 && n * 8 <= std::max(rows, 8); ++n) {
+        const int H = (rows + n - 1) / n, nseg = (rows + H - 1) / H;
+        const long long segs = (long long)best.nstrips * nseg, rounds = (segs + c->ncu - 1) / c->ncu;
+        const long long iters = (H + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
+        const long long cost = rounds * iters;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best.nsegy = nseg; best.H = H; }
+    }
+    return best;
+}
+
+int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_frame) {
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
+        const int F = c->tb_f, xe = c->geo.nx - F, ye = c->geo.ny - F;
+        const StreamPlan pl = plan_stream(c, S);
+        FramePtrs<R> fp;
+        fp.src = (const R*)c->lat[from];
+        for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+        const int L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
+        const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
+        hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(nframe + pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s,
+                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, F, xe, ye, pl.nstrips, pl.H,
+                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, ST_LDS_BYTES) ? 1 : 0);
+    });
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
 int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool with_frame = false) {
+    if (c->stream) return launch_stream(c, from, to, s, steps, with_frame);
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
@@ -285,7 +327,7 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
                 const int ntx = (xe - F + TX - 1) / TX, nty = (ye - F + TY - 1) / TY;
                 FramePtrs<R> fp;
                 fp.src = (const R*)c->lat[from];
-                for (int i = 0; i < 5; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+                for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
                 const int L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
                 const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
                 hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, VT::SEM, S, WIDE, VT::TURB>), dim3(nframe + ntx * nty, c->batch), dim3(512), 0, s,
@@ -831,7 +873,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return bail("bad semantics");
     if (p->turb != 0 && p->turb != 1) return bail("turb must be 0 or 1");
     if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return bail("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
-    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_PUSH) return bail("bad kernel variant");
+    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_STREAM) return bail("bad kernel variant");
     if (p->kernel == LBM_KERNEL_PUSH && (p->turb || p->batch > 1 || p->y0 != 0 || p->ny_local != p->ny))
         return bail("kernel = PUSH (the reference's two-launch scheme, for A/B) takes one whole lattice without the closure");
     if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
@@ -839,7 +881,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return bail("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
     if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return bail("a batch of lattices cannot be slab-decomposed");
     if (p->ny_local_min < 0 || p->ny_local_min > p->ny_local) return bail("ny_local_min must be 0 or the smallest ny_local of all ranks (<= ny_local)");
-    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > 5)) return bail("tb_steps must be 0 (default) or 2 .. 5");
+    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > ST_MAX_S)) return bail("tb_steps must be 0 (default) or 2 .. 8");
     if (p->frame_seg != 0 && p->frame_seg < 8) return bail("frame_seg must be 0 (default) or >= 8");
     if ((p->flags & LBM_FLAG_NT_ON) && (p->flags & LBM_FLAG_NT_OFF)) return bail("LBM_FLAG_NT_ON and LBM_FLAG_NT_OFF exclude each other");
     int ndev = 0;
@@ -912,8 +954,26 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const int want = p->tb_steps ? p->tb_steps : small_lone ? (p->dtype == LBM_F32 ? 5 : std::max(4, want64))
                                                                 : (p->dtype == LBM_F32 ? want32 : want64);
         const bool deep_ok = p->nx >= 64 && ny_plan >= 64;
-        c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
-        c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
+        // The strip-streaming kernel (lbm_stream.hpp): one workgroup per CU marches down a strip of 240 fp32 / 112 fp64 useful
+        // columns, up to 8 steps per launch, no rim in y.  It needs tall segments to amortise its pipeline fill, i.e. a large
+        // lattice: AUTO takes it for lone lattices from 3072^2 cells (profiles/r02_logs/stream_ab.log); kernel = STREAM forces it.
+        const bool can_stream = can_tb && deep_ok && c->batch == 1 && !slab;
+        if (p->kernel == LBM_KERNEL_STREAM && !can_stream)
+            return (delete c, bail("kernel = STREAM takes one whole lattice with nx % (16 / sizeof(real)) == 0, nx >= 64, ny >= 64"));
+        c->stream = can_stream && (p->kernel == LBM_KERNEL_STREAM || (p->kernel == LBM_KERNEL_AUTO && (long long)p->nx * ny_plan >= 3072LL * 3072));
+        if (c->stream) {
+            c->use_tb = true;
+            c->tb_steps = p->tb_steps ? p->tb_steps : ST_MAX_S;
+            c->tb_f = (c->tb_steps + 1 + 3) / 4 * 4;    // F >= S + 1, a multiple of the vector width: 4 (S <= 3), 8 (S <= 7), 12
+            while (c->tb_steps > 2 && (p->nx < 2 * c->tb_f + 16 || ny_plan < 2 * c->tb_f + 16)) {   // (tiny lattices: keep an interior)
+                c->tb_steps -= 1;
+                c->tb_f = (c->tb_steps + 1 + 3) / 4 * 4;
+            }
+        } else {
+            if (want > 5) return (delete c, bail("tb_steps 6 .. 8 need kernel = STREAM"));
+            c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
+            c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
+        }
         // tile shape of the three-step kernel, A/B in one run (profiles/r01_logs/perf14.log): 14 vectors x 28 rows beats
         // 30 x 12 by 5 % for fp32 MRT (less rim arithmetic), ties for fp64 and SRT.  (The wide variant is no longer compiled.)
         // measured (profiles/r01_logs/perf37.log, perf38.log): one launch per unit instead of S + 1 and no cross-stream dependency:
@@ -931,6 +991,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->lazy_lag = !(p->flags & LBM_FLAG_EAGER_LAG);
     }
     auto cleanup = [&](const std::string& m) -> lbm_ctx* { lbm_destroy(c); return bail(m); };
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) c->ncu = prop.multiProcessorCount;
+    }
     if ((e = hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
     {   // halo exchange stream at the highest priority: its (tiny) RCCL kernels must not queue behind the
         // thousands of workgroups of the interior kernel they are meant to overlap

@@ -100,12 +100,13 @@ __global__ __launch_bounds__(TB_NT) void k_step2_deep(const R* __restrict__ src,
 template <typename R>
 struct FramePtrs {
     const R* src;    // state n
-    R* pass[5];      // output of pass 1 .. S (pass[S - 1] = the destination lattice)
+    R* pass[8];      // output of pass 1 .. S (pass[S - 1] = the destination lattice)
 };
 
 template <typename R>
 __device__ __forceinline__ R* pass_ptr(const FramePtrs<R>& fp, int j) {   // (selects, not an indexed load: no private-memory copy)
-    return j == 0 ? fp.pass[0] : j == 1 ? fp.pass[1] : j == 2 ? fp.pass[2] : j == 3 ? fp.pass[3] : fp.pass[4];
+    return j == 0 ? fp.pass[0] : j == 1 ? fp.pass[1] : j == 2 ? fp.pass[2] : j == 3 ? fp.pass[3] : j == 4 ? fp.pass[4] : j == 5 ? fp.pass[5]
+                                                                                                 : j == 6 ? fp.pass[6] : fp.pass[7];
 }
 
 // LDS bytes a workgroup of the fused frame passes may use (= the tile kernel's buffer)

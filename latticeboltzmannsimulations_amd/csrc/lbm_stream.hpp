@@ -1,0 +1,224 @@
+// lbm_stream.hpp -- the large-lattice multi-step kernel: S time steps per launch, streamed down column strips.
+//
+// Why a second multi-step kernel: k_stepS_deep (lbm_kernels.hpp) cuts the interior into 2-D tiles; every tile re-reads and
+// re-computes a rim of S - 1 cells on all four sides (S = 5, fp32: 1.5 x the reads, 1.33 x the arithmetic; fp64 1.8 x), and a
+// workgroup alternates between a load phase, S compute phases and a store phase that only the second workgroup of the CU
+// overlaps.  Here a workgroup owns a column STRIP (one wave-row wide: 64 lanes x V cells = 256 fp32 / 128 fp64 cells) of a
+// tall segment of rows and marches down it; the rim exists in x only (R cells per side), rows are loaded once and stored once,
+// and loading, the S levels and storing are all in flight at the same time in different waves.
+//
+// Data flow.  Row y of the strip is a BLOCK held by one wave in registers (9 planes x V cells per lane -- the register file,
+// not LDS, is the big on-chip store: 512 KB per CU).  A block takes S updates; update l -> l + 1 of row y needs rows y - 1 and
+// y + 1 at level l.  Blocks are skewed in time: block b performs its update number l in iteration b + 2 l, so its neighbours
+// b - 1 and b + 1 have reached level l one iteration earlier and have not yet moved on by more than one level.  Neighbouring
+// rows talk through LDS: after an update a block posts the three planes that move up (cy = +1: k = 2, 5, 6; read by block
+// b - 1) and the three that move down (k = 4, 7, 8; read by block b + 1).  The upward post is consumed before the next post
+// overwrites it; the downward one is consumed one iteration after the next post, so it alternates between two buffers.  The
+// three planes that stay in the row (k = 0, 1, 3) never leave the registers: x -+ 1 neighbours come from the adjacent lane by
+// DPP (v_mov_b32 wave_shr / wave_shl, 4 cycles, no LDS).  The first update of a block pulls straight from the lattice (the nine
+// shifted loads of a single step), the last one stores to the lattice, and the wave then loads its next block (16 rows further
+// down): 2 S = 16 blocks are in flight per workgroup (16 waves), half of them updating in any one iteration -- two per SIMD.
+// ONE workgroup barrier per iteration; every LDS slot is written in even and read in odd iterations of its owner (or vice
+// versa), so no second barrier is needed.
+//
+// Per-cell arithmetic is collide_vec, the same operation sequence as every other kernel: results are bit-identical.
+// Lead-in: the first / last S - 1 rows of a segment run through the pipeline too; their higher levels are computed from rows
+// that are not there (stale LDS) -- garbage that never reaches a row of the segment itself (one row per level).  S is a
+// run-time argument (the loop body is the same for every level): one instantiation serves every unit length.
+#pragma once
+#include "lbm_kernels.hpp"
+
+constexpr int ST_WAVES = 16;            // waves per workgroup = blocks in flight
+constexpr int ST_NT = ST_WAVES * 64;
+constexpr int ST_MAX_S = ST_WAVES / 2;  // 8 steps per launch at most
+// LDS per wave: 3 upward planes + 2 x 3 downward planes, one wave-row (64 lanes x 16 B = 1 KiB) each
+constexpr int ST_LDS_BYTES = ST_WAVES * 9 * 1024;   // 144 KiB: one workgroup per CU
+
+// value of the lane below / above in the wave (lane 0 / 63 keep their own): one DPP move per 32-bit register
+__device__ __forceinline__ int dpp_from_lower(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ int dpp_from_upper(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+__device__ __forceinline__ float lane_lower(float v) { return __builtin_bit_cast(float, dpp_from_lower(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float lane_upper(float v) { return __builtin_bit_cast(float, dpp_from_upper(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ double lane_lower(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)dpp_from_lower((int)(unsigned)b), hi = (unsigned)dpp_from_lower((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_upper(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)dpp_from_upper((int)(unsigned)b), hi = (unsigned)dpp_from_upper((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// in[c] = own[c - 1] with own[-1] = the lower lane's own[V - 1]   (values that move towards +x)
+template <typename R, int V>
+__device__ __forceinline__ typename VecT<R, V>::type shift_from_lower(typename VecT<R, V>::type own) {
+    typename VecT<R, V>::type r;
+    r[0] = lane_lower(own[V - 1]);
+#pragma unroll
+    for (int c = 1; c < V; ++c) r[c] = own[c - 1];
+    return r;
+}
+// in[c] = own[c + 1] with own[V] = the upper lane's own[0]        (values that move towards -x)
+template <typename R, int V>
+__device__ __forceinline__ typename VecT<R, V>::type shift_from_upper(typename VecT<R, V>::type own) {
+    typename VecT<R, V>::type r;
+#pragma unroll
+    for (int c = 0; c < V - 1; ++c) r[c] = own[c + 1];
+    r[V - 1] = lane_upper(own[0]);
+    return r;
+}
+
+// rim cells per side of a strip for S steps (a multiple of the vector width)
+__host__ __device__ constexpr int stream_rim(int S, int V) { return (S + V - 1) / V * V; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL loads and stores
+// (s_waitcnt vmcnt(0)): here that would put the HBM round trip of the one wave that has just stored its row and prefetched the
+// next on the critical path of all sixteen, every iteration (measured: 2.4 us per iteration instead of 0.7).  The prefetched
+// registers are waited for where they are used (the compiler's own s_waitcnt vmcnt before the first update of the block).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename R, int COLL, bool TURB>
+__device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo, const Relax<R>& w, R* __restrict__ lds,
+                                               int S, int xs, int ya, int yb, int xe) {
+    constexpr int V = 16 / (int)sizeof(R), ROW = 64 * V;        // cells of a wave-row
+    typedef typename VecT<R, V>::type T;
+    // (the wave index is made a scalar: everything derived from it -- the block's row, the row base addresses, the LDS slots -- then
+    // lives in SGPRs, and the global accesses take the scalar-base + 32-bit lane offset form)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // blocks are dealt to waves so that consecutive blocks (which update in alternate iterations) sit on the same SIMDs:
+    // hardware wave w goes to SIMD w % 4 (cyclically), block slot q = 2 (w % 8) + w / 8 -> each SIMD gets two even and two odd slots
+    const int q = ((wv & 7) << 1) | (wv >> 3);
+    const int RV = stream_rim(S, V) / V;                          // rim, in vector cells
+    const int nb = (yb - ya) + 2 * (S - 1);                       // blocks (rows) that go through the pipeline
+    const int y_first = ya - (S - 1);
+    const int x0 = xs + lane * V;
+    const bool lane_in = x0 < geo.nx;                             // (the last strip may reach beyond the lattice)
+    const bool lane_out = lane >= RV && lane < 64 - RV && x0 < xe;
+    R* const up_mine = lds + (q * 9) * ROW + lane * V;            // slots: [0..2] up (k = 2, 5, 6), [3..5] down buffer 0, [6..8] down buffer 1
+    const R* const up_below = lds + (((q + 1) & (ST_WAVES - 1)) * 9) * ROW + lane * V;
+    const R* const down_above = lds + (((q + ST_WAVES - 1) & (ST_WAVES - 1)) * 9 + 3) * ROW + lane * V;
+
+    T in[Q], outv[Q], hq, hr;
+    // address = scalar row base (SGPR pair) + unsigned 32-bit lane offset: the global_load / global_store "saddr" form, one
+    // offset VGPR instead of a 64-bit address pair per plane
+    auto row_base = [&](const R* p, int k, int y) { return (const char*)(p + ((long long)k * geo.plane + (long long)(y + GHY) * geo.row)); };
+    const unsigned lane_off = (unsigned)(GH + x0) * (unsigned)sizeof(R);
+    auto cell = [&](const char* base, int dx) {
+        unsigned off = lane_off;
+        asm volatile("" : "+v"(off));      // (opaque: keeps base + offset from being hoisted out of the block loop as a 64-bit per-lane address)
+        return (const R*)(base + (off + (unsigned)(dx * (int)sizeof(R))));
+    };
+    auto load_row = [&](int y) {    // the nine pulls of a single step, straight from the lattice (level 0 -> 1)
+        if (!lane_in) return;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) in[k] = vload<R, V, false>(cell(row_base(src, k, y + cyk(k)), -cxk(k)), cxk(k) == 0);
+        if (TURB) {
+            hq = vload<R, V, false>(cell(row_base(src, K_QEQ, y), 0), true);
+            hr = vload<R, V, false>(cell(row_base(src, K_RHO, y), 0), true);
+        }
+    };
+    auto post = [&](int level) {    // level reached: 1 .. S - 1
+        R* const dn = up_mine + (3 + (level & 1) * 3) * ROW;
+        *reinterpret_cast<T*>(up_mine) = outv[2];
+        *reinterpret_cast<T*>(up_mine + ROW) = outv[5];
+        *reinterpret_cast<T*>(up_mine + 2 * ROW) = outv[6];
+        *reinterpret_cast<T*>(dn) = outv[4];
+        *reinterpret_cast<T*>(dn + ROW) = outv[7];
+        *reinterpret_cast<T*>(dn + 2 * ROW) = outv[8];
+    };
+#pragma unroll
+    for (int k = 0; k < Q; ++k) in[k] = T{};
+    hq = T{}; hr = T{};
+    // The schedule of one wave is static: q idle iterations, then per block 16 iterations = S x (update, idle) + 16 - 2 S idle
+    // ones, then idle ones up to the common total; every iteration ends with the workgroup barrier (one per iteration for every
+    // wave).  Written as loops over blocks and levels -- not as one loop over iterations with a test -- so that the prefetched
+    // row (in[]) is live only between two blocks and the carried planes (outv[0], [1], [3]) only inside a block.
+    const int jtot = (nb + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
+    int done = q;
+    for (int i = 0; i < q; ++i) lds_barrier();
+    if (q < nb) load_row(y_first + q);
+    for (int b = q; b < nb; b += ST_WAVES) {
+        collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);                       // level 0 -> 1, from the prefetched pulls
+        if (S > 1) post(1);
+        lds_barrier();
+        lds_barrier();
+        for (int l = 1; l < S; ++l) {                                             // level l -> l + 1
+            const R* const dn = down_above + (l & 1) * 3 * ROW;
+            in[0] = outv[0];
+            in[1] = shift_from_lower<R, V>(outv[1]);
+            in[3] = shift_from_upper<R, V>(outv[3]);
+            in[2] = *reinterpret_cast<const T*>(up_below);
+            in[5] = shift_from_lower<R, V>(*reinterpret_cast<const T*>(up_below + ROW));
+            in[6] = shift_from_upper<R, V>(*reinterpret_cast<const T*>(up_below + 2 * ROW));
+            in[4] = *reinterpret_cast<const T*>(dn);
+            in[7] = shift_from_upper<R, V>(*reinterpret_cast<const T*>(dn + ROW));
+            in[8] = shift_from_lower<R, V>(*reinterpret_cast<const T*>(dn + 2 * ROW));
+            collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr);
+            if (l + 1 < S) {
+                post(l + 1);
+                lds_barrier();
+                lds_barrier();
+            }
+        }
+        {   // level S reached: prefetch this wave's next block (first: nothing it waits for is behind the stores), then store
+            const int y = y_first + b;
+            const T hq_done = hq, hr_done = hr;      // (the prefetch overwrites the history registers)
+            if (b + ST_WAVES < nb) load_row(y_first + b + ST_WAVES);
+            if (lane_out && y >= ya && y < yb) {
+#pragma unroll
+                for (int k = 0; k < Q; ++k) vstore<R, V, false>(const_cast<R*>(cell(row_base(dst, k, y), 0)), outv[k]);
+                if (TURB) {
+                    vstore<R, V, false>(const_cast<R*>(cell(row_base(dst, K_QEQ, y), 0)), hq_done);
+                    vstore<R, V, false>(const_cast<R*>(cell(row_base(dst, K_RHO, y), 0)), hr_done);
+                }
+            }
+            if (S > 1) { lds_barrier(); lds_barrier(); }
+        }
+        for (int i = 2 * S; i < ST_WAVES; ++i) lds_barrier();
+        done += ST_WAVES;
+    }
+    for (; done < jtot; ++done) lds_barrier();
+}
+
+// grid: [nframe frame workgroups (a lone lattice)] + nstrips * nsegy segments.  S <= ST_MAX_S steps; F = frame width (>= S + 1,
+// a multiple of the vector width); a strip's useful columns are [xs + R, xs + 64 V - R), the first strip's start at F.
+template <typename R, int COLL, int SEM, bool TURB>
+__global__ __launch_bounds__(ST_NT) void k_stream(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int S, int F, int xe, int ye,
+                                                  int nstrips, int H, FramePtrs<R> fp, int nframe, int nsegx, int nsegy, int seg, int use_lds) {
+    __shared__ __align__(16) R lds[ST_LDS_BYTES / sizeof(R)];
+    if ((int)blockIdx.x < nframe) {
+        frame_passes<R, COLL, SEM, TURB, ST_NT>(fp, 0, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg, use_lds ? lds : nullptr);
+        return;
+    }
+    constexpr int V = 16 / (int)sizeof(R);
+    const int b = blockIdx.x - nframe;
+    const int strip = b % nstrips, sy = b / nstrips;
+    const int R_ = stream_rim(S, V);
+    const int xs = F - R_ + strip * (64 * V - 2 * R_);
+    const int ya = F + sy * H, yb = min(ye, ya + H);
+    if (ya >= yb) return;
+    stream_segment<R, COLL, TURB>(src, dst, geo, w, lds, S, xs, ya, yb, xe);
+}
+
+// explicit instantiations live in lbm_stream_f32.hip / lbm_stream_f64.hip (LBM_STREAM_EXTERN empty there)
+#ifndef LBM_SINGLE_TU
+#ifndef LBM_STREAM_EXTERN
+#define LBM_STREAM_EXTERN extern
+#endif
+#define LBM_STREAM_ONE(R, COLL, SEM, TURB)                                                                               \
+    LBM_STREAM_EXTERN template __global__ void k_stream<R, COLL, SEM, TURB>(const R* __restrict__, R* __restrict__, Geo, Relax<R>, int, int, int, int, \
+                                                                          int, int, FramePtrs<R>, int, int, int, int, int);
+#define LBM_STREAM_ALL(R)                                                                                                \
+    LBM_STREAM_ONE(R, C_SRT, SEM_GPU, false) LBM_STREAM_ONE(R, C_TRT, SEM_GPU, false) LBM_STREAM_ONE(R, C_MRT, SEM_GPU, false)          \
+    LBM_STREAM_ONE(R, C_MRT_FAST, SEM_GPU, false) LBM_STREAM_ONE(R, C_SRT_FAST, SEM_GPU, false) LBM_STREAM_ONE(R, C_TRT_FAST, SEM_GPU, false) \
+    LBM_STREAM_ONE(R, C_SRT, SEM_GPU, true) LBM_STREAM_ONE(R, C_TRT, SEM_GPU, true) LBM_STREAM_ONE(R, C_MRT, SEM_GPU, true)             \
+    LBM_STREAM_ONE(R, C_MRT_FAST, SEM_GPU, true) LBM_STREAM_ONE(R, C_SRT_FAST, SEM_GPU, true) LBM_STREAM_ONE(R, C_TRT_FAST, SEM_GPU, true) \
+    LBM_STREAM_ONE(R, C_SRT, SEM_PY, false) LBM_STREAM_ONE(R, C_TRT, SEM_PY, false) LBM_STREAM_ONE(R, C_MRT, SEM_PY, false)
+#if !defined(LBM_STREAM_ONLY_F64)
+LBM_STREAM_ALL(float)
+#endif
+#if !defined(LBM_STREAM_ONLY_F32)
+LBM_STREAM_ALL(double)
+#endif
+#endif  // LBM_SINGLE_TU

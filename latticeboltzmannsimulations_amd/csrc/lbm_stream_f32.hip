@@ -1,0 +1,4 @@
+// lbm_stream_f32.hip -- explicit instantiations of the strip-streaming multi-step kernel, float (see lbm_stream.hpp)
+#define LBM_STREAM_EXTERN
+#define LBM_STREAM_ONLY_F32
+#include "lbm_stream.hpp"

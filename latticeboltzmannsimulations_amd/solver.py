@@ -12,7 +12,7 @@ _DT = {np.dtype(np.float32): L.LBM_F32, np.dtype(np.float64): L.LBM_F64}
 _COLL = {"SRT": L.LBM_SRT, "TRT": L.LBM_TRT, "MRT": L.LBM_MRT}
 _SEM = {"mrt_py": L.LBM_SEM_MRT_PY, "mrt_gpu": L.LBM_SEM_MRT_GPU}
 _KERNEL = {"auto": L.LBM_KERNEL_AUTO, "generic": L.LBM_KERNEL_GENERIC, "vec": L.LBM_KERNEL_VEC, "tb": L.LBM_KERNEL_TB,
-           "push": L.LBM_KERNEL_PUSH}
+           "push": L.LBM_KERNEL_PUSH, "stream": L.LBM_KERNEL_STREAM}
 _ARITH = {"strict": L.LBM_ARITH_STRICT, "fast": L.LBM_ARITH_FAST}
 _LAYOUT = {"auto": L.LBM_LAYOUT_AUTO, "planes": L.LBM_LAYOUT_PLANES, "rows": L.LBM_LAYOUT_ROWS}
 

@@ -52,7 +52,7 @@ def test_params_struct_layout():
 def test_enums_match_header():
     src = open(os.path.join(ROOT, "include", "lbm.h")).read()
     for name in ("LBM_F32", "LBM_F64", "LBM_SRT", "LBM_TRT", "LBM_MRT", "LBM_SEM_MRT_PY", "LBM_SEM_MRT_GPU",
-                 "LBM_KERNEL_AUTO", "LBM_KERNEL_GENERIC", "LBM_KERNEL_VEC", "LBM_KERNEL_TB", "LBM_KERNEL_PUSH", "LBM_SIDE_LOW", "LBM_SIDE_HIGH",
+                 "LBM_KERNEL_AUTO", "LBM_KERNEL_GENERIC", "LBM_KERNEL_VEC", "LBM_KERNEL_TB", "LBM_KERNEL_PUSH", "LBM_KERNEL_STREAM", "LBM_SIDE_LOW", "LBM_SIDE_HIGH",
                  "LBM_LAYOUT_AUTO", "LBM_LAYOUT_PLANES", "LBM_LAYOUT_ROWS", "LBM_ARITH_STRICT", "LBM_ARITH_FAST",
                  "LBM_FLAG_NO_DEEP_HALO", "LBM_FLAG_FRAME_UNFUSED", "LBM_FLAG_FRAME_FUSED_BATCH", "LBM_FLAG_NO_FRAME_LDS",
                  "LBM_FLAG_NT_ON", "LBM_FLAG_NT_OFF", "LBM_FLAG_COMM_PRIORITY_OFF", "LBM_FLAG_EAGER_LAG"):

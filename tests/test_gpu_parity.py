@@ -178,6 +178,23 @@ def test_one_step_lag_after_every_kind_of_last_unit(dtype, coll, turb):
             assert tau.min() >= (1.0 / s.relax["omega"]) * (1 - 1e-6) and tau.max() > tau.min()
 
 
+@pytest.mark.parametrize("sem,coll,turb", [("mrt_gpu", "MRT", 0), ("mrt_gpu", "SRT", 1), ("mrt_gpu", "TRT", 0), ("mrt_py", "SRT", 0), ("mrt_gpu", "MRT", 1)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_streaming_kernel_is_bit_identical_to_oracle(sem, coll, turb, dtype):
+    """kernel='stream' (lbm_stream.hpp): up to 8 time steps per launch streamed down column strips -- rows in registers,
+    neighbour rows through LDS, x neighbours by DPP.  Sizes with one and several strips (partial last strip), one and several
+    row segments, every steps-per-launch setting 2 .. 8 (frame widths 4 / 8 / 12), call lengths that leave every remainder
+    (tail units of 3 .. 7 steps, single steps), fields read after units of every length (lagged lattice recomputed by the same
+    kernel)."""
+    for nx, ny, tbs in ((320, 192, 8), (1028, 80, 0), (132, 600, 5), (516, 300, 7), (260, 131, 2), (64, 64, 8), (772, 257, 6), (304, 99, 3), (288, 160, 4)):
+        o = CavityOracleC(nx, ny, 1000.0, semantics=sem, collision=coll, dtype=dtype, turb=turb)
+        with CavitySolver(nx, ny, 1000.0, RT=coll, semantics=sem, dtype=dtype, turb=turb, kernel="stream", tuning=dict(tb_steps=tbs)) as s:
+            for n in (1, 8, 19, 3, 7, 12):
+                o.step(n); s.step(n)
+                same(s, o, f"stream {nx}x{ny} tb_steps={tbs} {sem} {coll} turb={turb} after {o.nsteps} steps")
+            assert s.next_unit(100) == (tbs or 8) or min(nx, ny) < 80
+
+
 def test_seeded_random_configurations_against_oracle():
     """40 seeded random (size, steps, semantics, collision, dtype, kernel, layout, turb) draws; every kernel variant must
     reproduce the oracle bit for bit, including ragged sizes and step counts that mix 1-, 2- and 3-step launches."""
