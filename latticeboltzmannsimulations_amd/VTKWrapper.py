@@ -5,7 +5,10 @@ raw appended binary blocks (UInt64 block headers, little endian, x fastest), cel
 
 tests/test_host_logic.py compares the bytes with files produced by the reference's own writer
 (tests/golden/vtr_*.npz).  Like the reference, X*Y cell values are attached to the grid whose
-points are ``grid`` (so the extent is 0..X-1, 0..Y-1, 0..0) -- kept as is for drop-in parity.
+points are ``grid`` (so the extent is 0..X-1, 0..Y-1, 0..0) -- kept as is for drop-in parity: that
+grid has only (X-1)*(Y-1) cells (MRT.py:91-94,606-610 vs pyevtk/hl.py:152-153), so readers see a
+size mismatch.  ``correct=True`` writes the same arrays as POINT data of the same grid -- one value
+per lattice node, which is what the X*Y values are -- and is the mode to use for new output.
 """
 import numpy as np
 
@@ -20,9 +23,11 @@ def _tname(a):
         raise TypeError(f"unsupported dtype for VTK output: {np.asarray(a).dtype}")
 
 
-def saveToVTK(velocity, rho, prefix, saveNumber, grid):
+def saveToVTK(velocity, rho, prefix, saveNumber, grid, correct=False):
     """velocity: (ux, uy, uz) arrays of shape [X, Y, 1]; rho: [X, Y, 1]; grid: (x, y, z)
-    coordinate vectors.  Writes ./{prefix}.{saveNumber}.vtr and returns its path."""
+    coordinate vectors.  Writes ./{prefix}.{saveNumber}.vtr and returns its path.
+    correct=False: byte-identical to the reference's writer (cell data, see the module text);
+    correct=True: the values as point data of the same grid (a consistent file)."""
     name = "./" + prefix + "." + saveNumber + ".vtr"
     x, y, z = (np.ascontiguousarray(g) for g in grid)
     vx, vy, vz = (np.asarray(v) for v in velocity)
@@ -32,6 +37,8 @@ def saveToVTK(velocity, rho, prefix, saveNumber, grid):
     if not (vx.dtype == vy.dtype == vz.dtype):
         raise ValueError("velocity components must share one dtype")
     ncells = vx.size
+    if correct and vx.shape != (x.size, y.size, z.size):
+        raise ValueError("correct=True: one value per grid point, i.e. arrays of shape (len(x), len(y), len(z))")
     end = (x.size - 1, y.size - 1, z.size - 1)
     ext = "%d %d %d %d %d %d" % (0, end[0], 0, end[1], 0, end[2])
 
@@ -54,12 +61,13 @@ def saveToVTK(velocity, rho, prefix, saveNumber, grid):
         hdr.append('<DataArray Name="%s" NumberOfComponents="1" type="%s" format="appended" offset="%d"/>\n'
                    % (nm, _tname(a), o))
     hdr.append('</Coordinates>\n')
-    hdr.append('<CellData scalars="velocity">\n')
+    section = "PointData" if correct else "CellData"
+    hdr.append('<%s scalars="velocity">\n' % section)
     hdr.append('<DataArray Name="velocity" NumberOfComponents="3" type="%s" format="appended" offset="%d"/>\n'
                % (_tname(vx), off_vel))
     hdr.append('<DataArray Name="pressure" NumberOfComponents="1" type="%s" format="appended" offset="%d"/>\n'
                % (_tname(rho), off_p))
-    hdr.append('</CellData>\n')
+    hdr.append('</%s>\n' % section)
     hdr.append('</Piece>\n')
     hdr.append('</RectilinearGrid>\n')
     hdr.append('<AppendedData encoding="raw">\n_')

@@ -24,7 +24,7 @@ import numpy as np
 from .solver import CavityBatch
 
 
-def _solve_batch(idx, Re_range, xsize, ysize, RT, turb, uLB, maxIt, Pinterval, tolerance, device, dtype, say, out, arith):
+def _solve_batch(idx, Re_range, xsize, ysize, RT, turb, uLB, maxIt, Pinterval, tolerance, device, dtype, say, out, arith, convergence="host"):
     """Runs the lattices Re_range[idx] in lock step; fills out = (f_final, u_final, its) rows idx.  The per-lattice logic is
     the reference's loop body (MRT_GPU_datagen.py:707-731,862-871): a check after iteration It = 0, Pinterval, 2 Pinterval, ...
     (i.e. after It + 1 steps), `count` consecutive-or-not hits of |mean(u) - mean(u_past)| / uLB < tolerance, stop at count > 5."""
@@ -37,10 +37,13 @@ def _solve_batch(idx, Re_range, xsize, ysize, RT, turb, uLB, maxIt, Pinterval, t
         It = 0
         while open_:
             b.step(It + 1 - b.steps_done)
-            u, _ = b.get_fields(out_dtype=np.float32)
+            # the check value: NumPy's float32 mean of the downloaded field (the reference's own definition), or the mean reduced on
+            # the device in double -- B doubles cross PCIe instead of B fields; the fields are then fetched only when a lattice stops
+            means = b.mean_u() if convergence == "device" else None
+            u = None if convergence == "device" else b.get_fields(out_dtype=np.float32)[0]
             finished = []
             for j in sorted(open_):
-                mean_u = float(np.mean(u[j]))
+                mean_u = float(means[j]) if convergence == "device" else float(np.mean(u[j]))
                 say("current Re is " + str(Re_range[idx[j]]) + " and iteration is " + str(It))
                 say("current mean u is " + str(mean_u / uLB))
                 if abs(mean_u - past[j]) / uLB < tolerance:
@@ -51,6 +54,8 @@ def _solve_batch(idx, Re_range, xsize, ysize, RT, turb, uLB, maxIt, Pinterval, t
                 past[j] = mean_u
             last = It + Pinterval > maxIt - 1          # no further check: the rest finishes the loop like the reference
             if finished:
+                if u is None:
+                    u = b.get_fields(out_dtype=np.float32)[0]
                 fin = b.get_fields(want_fin=True, out_dtype=np.float32)[2]
                 for j in finished:
                     f_final[idx[j]], u_final[idx[j]], its[idx[j]] = fin[j], u[j], b.steps_done
@@ -69,7 +74,7 @@ def _solve_batch(idx, Re_range, xsize, ysize, RT, turb, uLB, maxIt, Pinterval, t
 
 def generate(Re_range=None, xsize=32 * 12, ysize=32 * 12, RT="SRT", turb=1, uLB=0.08, maxIt=3000000, Pinterval=10000,
              tolerance=0.0000001, OutputFolder="./output", save=True, concurrent=64, devices=(0,), dtype=np.float32,
-             quiet=False, arith="strict"):
+             quiet=False, arith="strict", convergence="host"):
     """Returns (feq_initial, f_final, u_final, Re_range, iterations_per_Re); writes the four .npy files when `save`."""
     say = (lambda *a: None) if quiet else print
     Re_range = np.arange(100, 5100, 10) if Re_range is None else np.asarray(Re_range)   # MRT_GPU_datagen.py:55
@@ -81,7 +86,7 @@ def generate(Re_range=None, xsize=32 * 12, ysize=32 * 12, RT="SRT", turb=1, uLB=
 
     def work(k):
         return _solve_batch(chunks[k], Re_range, xsize, ysize, RT, turb, uLB, maxIt, Pinterval, tolerance,
-                            devices[k % len(devices)], dtype, say, out, arith)
+                            devices[k % len(devices)], dtype, say, out, arith, convergence)
     if len(devices) > 1 and len(chunks) > 1:
         with ThreadPoolExecutor(max_workers=len(devices)) as pool:      # lbm_step runs in C with the GIL released
             feq = list(pool.map(work, range(len(chunks))))
@@ -110,9 +115,11 @@ def main(argv=None):
     ap.add_argument("--maxIt", type=int, default=3000000)
     ap.add_argument("--OutputFolder", default="./output")
     ap.add_argument("--arith", choices=["strict", "fast"], default="strict", help="fast: agrees with strict to rounding, ~1.3x faster")
+    ap.add_argument("--convergence", choices=["host", "device"], default="host",
+                    help="device: the convergence test on lbm_mean_u (reduced on the GPU) instead of the downloaded field")
     a = ap.parse_args(argv)
     generate(np.arange(*a.Re), xsize=a.size, ysize=a.size, concurrent=a.concurrent, Pinterval=a.Pinterval, maxIt=a.maxIt,
-             OutputFolder=a.OutputFolder, arith=a.arith)
+             OutputFolder=a.OutputFolder, arith=a.arith, convergence=a.convergence)
     return 0
 
 

@@ -37,7 +37,10 @@ class CavityResult:
         self.mlups = 0.0
 
 
-def _dashboard(path, u, rho, It, hist, Re, RT, regime, BC, xsize, ysize, uLB, relax):
+CS2_EFFECTIVE, CS_BULK = 0.025, 0.16     # MRT_GPU.py:350,374-376: Van Driest damping is overwritten by Cs2 = 0.025
+
+
+def _dashboard(path, u, rho, It, hist, Re, RT, regime, BC, xsize, ysize, uLB, relax, tau_mean=None):
     """PNG dashboard of MRT_GPU.py:786-870 (centreline plots vs Ghia, streamlines with vortex
     markers, regression history, parameter text)."""
     import matplotlib
@@ -79,6 +82,8 @@ def _dashboard(path, u, rho, It, hist, Re, RT, regime, BC, xsize, ysize, uLB, re
     s4.set_xlabel("time iteration", fontsize=20); s4.set_ylabel("Regression value", fontsize=20)
     pyplot.figtext(0.5, 0.3, "Current Regression value is")
     pyplot.figtext(0.5, 0.28, str(round(hist[-1][1], 4)))
+    pyplot.figtext(0.65, 0.45, "Square dots in above figure represent vortex locations from Ghia data")       # MRT_GPU.py:846-847
+    pyplot.figtext(0.65, 0.43, "Circular dots represent vortex locations of current simulation")
     pyplot.figtext(0.65, 0.35, "LBM parameters: " + RT, fontsize=20)
     pyplot.figtext(0.65, 0.31, "Grid size: " + str(xsize) + "*" + str(ysize))
     pyplot.figtext(0.65, 0.29, "Re: " + str(Re) + "    " + "BoundaryCondition: " + BC)
@@ -92,6 +97,12 @@ def _dashboard(path, u, rho, It, hist, Re, RT, regime, BC, xsize, ysize, uLB, re
     else:
         pyplot.figtext(0.65, 0.23, "omega_nu, omega_e, omega_eps, omega_q: ")
         pyplot.figtext(0.65, 0.21, " , ".join(str(round(relax[k], 3)) for k in ("omega", "omega_e", "omega_eps", "omega_q")))
+    if tau_mean is not None:
+        # MRT_GPU.py:862-866.  The reference prints these two lines under its `regime == 'Turbulent'` label (which it assigns to
+        # turb = 0, lines 277-280) from host names that do not exist (`Cs`, `Csbulk`: NameError) and from a `tauS` that is never
+        # downloaded; here they appear when the closure is on, with the constant the kernel really uses and the mean of taus_g.
+        pyplot.figtext(0.65, 0.17, "Smagorinsky constant, Cs = " + str(round(CS2_EFFECTIVE ** 0.5, 4)) + " at wall to " + str(CS_BULK) + " at bulk")
+        pyplot.figtext(0.65, 0.15, "Mean relaxation time, tau+tau_turbulent, is  " + str(tau_mean))
     f.suptitle("Lid Driven Cavity - Re" + str(int(Re)) + " " + regime + " " + RT + " " + BC + " " + str(xsize) + "*"
                + str(ysize), fontsize=30, y=1.04)
     pyplot.savefig(path, bbox_inches="tight", pad_inches=0.4)
@@ -100,13 +111,20 @@ def _dashboard(path, u, rho, It, hist, Re, RT, regime, BC, xsize, ysize, uLB, re
 
 def run_cavity(maxIt=3000000, Re=10000.0, RT="SRT", turb=1, xsize=32 * 5, ysize=32 * 5, uLB=0.08,
                Pinterval=3000, SavePlot=True, SaveVTK=False, project="ldc", OutputFolder="./output",
-               dtype=np.float32, semantics="mrt_gpu", device=0, quiet=False, solver_factory=None, arith="strict"):
+               dtype=np.float32, semantics="mrt_gpu", device=0, quiet=False, solver_factory=None, arith="strict",
+               convergence="host", vtk_correct=False):
     """Run the lid-driven cavity like MRT_GPU.py does; returns a :class:`CavityResult`.
 
     Argument names and defaults are the module constants of MRT_GPU.py:38-58.
     xsize / ysize need not be multiples of 32 here.  `solver_factory` (default: CavitySolver, i.e. liblbm_hip.so)
     exists so that this driver logic -- output iterations, metrics, files, convergence stop -- can be unit-tested
-    with a stand-in stepper; it is not a fallback: nothing in this package provides another stepper."""
+    with a stand-in stepper; it is not a fallback: nothing in this package provides another stepper.
+    convergence: 'host' (default) -- the reference's test as written, on NumPy's float32 mean of the downloaded u
+    (MRT_GPU.py:883-889); 'device' -- the same test on lbm_mean_u(), the mean reduced on the GPU in double (8 bytes cross
+    PCIe instead of the field; the two means differ in the last bits of a float, so a run may stop one check apart).
+    vtk_correct: write the .vtr files as point data (VTKWrapper.saveToVTK(correct=True)) instead of the reference's layout."""
+    if convergence not in ("host", "device"):
+        raise ValueError("convergence must be 'host' or 'device'")
     say = (lambda *a: None) if quiet else print
     tstart = timer()
     say("the value of uLB is ", uLB)
@@ -139,6 +157,7 @@ def run_cavity(maxIt=3000000, Re=10000.0, RT="SRT", turb=1, xsize=32 * 5, ysize=
     BC = "EB-NEBB "
     res = CavityResult()
     u = np.zeros((2, xsize, ysize), dtype=np.float32)
+    mean_past = 0.0
     count = 0
     done = 0          # iterations performed
     have_ghia = int(round(float(Re))) in ghia.RE_COLUMNS
@@ -162,19 +181,26 @@ def run_cavity(maxIt=3000000, Re=10000.0, RT="SRT", turb=1, xsize=32 * 5, ysize=
                 say("current regression value is " + str(reg_val))
             say("current mean velocity value is " + str(np.mean(u) / uLB))
             if SavePlot and have_ghia:
+                tau_mean = float(np.mean(solver.get_tau())) if (turb == 1 and hasattr(solver, "get_tau")) else None
                 _dashboard(os.path.join(OutputFolder, project + "_" + str(int(It / Pinterval)).zfill(5) + ".png"),
-                           u, rho, It, res.regression, Re, RT, regime, BC, xsize, ysize, uLB, relax)
+                           u, rho, It, res.regression, Re, RT, regime, BC, xsize, ysize, uLB, relax, tau_mean)
             if SaveVTK:
                 Vel = np.reshape(u, (2, xsize, ysize, 1))
                 cwd = os.getcwd()
                 os.chdir(OutputFolder)
                 try:
                     saveToVTK((Vel[0], Vel[1], velZ), np.reshape(rho, (xsize, ysize, 1)), project,
-                              str(int(It / Pinterval)).zfill(5), grid)
+                              str(int(It / Pinterval)).zfill(5), grid, correct=vtk_correct)
                 finally:
                     os.chdir(cwd)
             say("time elapsed is ", (timer() - tstart), "seconds")
-            if abs(np.mean(u) - np.mean(u_past)) / uLB < 0.00000001:      # MRT_GPU.py:883-889
+            if convergence == "device":
+                mean_now = solver.mean_u()
+                hit = abs(mean_now - mean_past) / uLB < 0.00000001
+                mean_past = mean_now
+            else:
+                hit = abs(np.mean(u) - np.mean(u_past)) / uLB < 0.00000001      # MRT_GPU.py:883-889
+            if hit:
                 count = count + 1
                 if count > 5:
                     say("breaking out of loop because of convergence")
@@ -211,10 +237,13 @@ def main(argv=None):
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
     ap.add_argument("--semantics", choices=["mrt_gpu", "mrt_py"], default="mrt_gpu")
     ap.add_argument("--arith", choices=["strict", "fast"], default="strict")
+    ap.add_argument("--convergence", choices=["host", "device"], default="host")
+    ap.add_argument("--vtk-correct", action="store_true", help="write .vtr point data (consistent file) instead of the reference's layout")
     a = ap.parse_args(argv)
     r = run_cavity(maxIt=a.maxIt, Re=a.Re, RT=a.RT, turb=a.turb, xsize=a.xsize, ysize=a.ysize, uLB=a.uLB,
                    Pinterval=a.Pinterval, SavePlot=not a.no_plot, SaveVTK=a.vtk, project=a.project,
-                   OutputFolder=a.OutputFolder, dtype=np.dtype(a.dtype), semantics=a.semantics, arith=a.arith)
+                   OutputFolder=a.OutputFolder, dtype=np.dtype(a.dtype), semantics=a.semantics, arith=a.arith,
+                   convergence=a.convergence, vtk_correct=a.vtk_correct)
     print("MLUPS : ", r.mlups)
     return 0
 

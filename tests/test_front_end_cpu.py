@@ -14,6 +14,7 @@ from oracle.lbm_ref import CavityOracleC
 class OracleStepper:
     """Same surface as CavitySolver as far as run_cavity uses it."""
     calls = []
+    mean_calls = 0
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0, device=0):
         self.o = CavityOracleC(xsize, ysize, Re, uLB=uLB, semantics=semantics, collision=RT, dtype=dtype, turb=turb)
@@ -30,6 +31,13 @@ class OracleStepper:
 
     def get_fields(self, out_dtype=None, **kw):
         return self.o.u.astype(out_dtype), self.o.rho.astype(out_dtype)
+
+    def mean_u(self):          # lbm_mean_u: the mean accumulated in double
+        OracleStepper.mean_calls += 1
+        return float(np.mean(self.o.u.astype(np.float64)))
+
+    def get_tau(self):
+        return np.full(self.o.rho.shape, 1.0 / self.relax["omega"] + 0.01)
 
     def close(self):
         pass
@@ -61,6 +69,43 @@ def test_convergence_stop(tmp_path, monkeypatch, capsys):
                    dtype=np.float64, solver_factory=OracleStepper)
     assert r.converged and r.iterations < 10 ** 6
     assert "breaking out of loop because of convergence" in capsys.readouterr().out
+
+
+def test_convergence_on_the_device_mean_stops_within_one_check_of_the_host_criterion(tmp_path, monkeypatch):
+    """convergence='device': the same test on lbm_mean_u (reduced in double on the GPU) instead of NumPy's float32 mean of the
+    downloaded field.  The two means differ in the last bits of a float, so the six hits may complete one check apart."""
+    monkeypatch.chdir(tmp_path)
+    kw = dict(maxIt=10 ** 7, Re=100.0, RT="MRT", turb=0, xsize=16, ysize=16, Pinterval=400, SavePlot=False, SaveVTK=True,
+              dtype=np.float64, solver_factory=OracleStepper, quiet=True)
+    host = run_cavity(**kw)
+    OracleStepper.mean_calls = 0
+    dev = run_cavity(convergence="device", **kw)
+    assert host.converged and dev.converged and OracleStepper.mean_calls >= 6
+    assert abs(dev.iterations - host.iterations) <= 400
+    with pytest.raises(ValueError):
+        run_cavity(convergence="gpu", **kw)
+
+
+def test_dashboard_carries_the_reference_legend_and_closure_lines(tmp_path, monkeypatch):
+    """MRT_GPU.py:846-847 (two legend lines) and 862-866 (Smagorinsky constant, mean relaxation time from taus_g)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import pyplot
+    texts = []
+    real = pyplot.figtext
+    monkeypatch.setattr(pyplot, "figtext", lambda x, y, s, **kw: (texts.append((round(x, 2), round(y, 2), s)), real(x, y, s, **kw))[1])
+    monkeypatch.chdir(tmp_path)
+    run_cavity(maxIt=1, Re=100.0, RT="SRT", turb=1, xsize=32, ysize=32, Pinterval=100, SavePlot=True, SaveVTK=False,
+               solver_factory=OracleStepper, quiet=True)
+    assert (0.65, 0.45, "Square dots in above figure represent vortex locations from Ghia data") in texts
+    assert (0.65, 0.43, "Circular dots represent vortex locations of current simulation") in texts
+    assert any(t[:2] == (0.65, 0.17) and t[2].startswith("Smagorinsky constant, Cs = 0.1581 at wall to 0.16 at bulk") for t in texts)
+    assert any(t[:2] == (0.65, 0.15) and t[2].startswith("Mean relaxation time, tau+tau_turbulent, is  ") for t in texts)
+    texts.clear()
+    run_cavity(maxIt=1, Re=100.0, RT="MRT", turb=0, xsize=32, ysize=32, Pinterval=100, SavePlot=True, SaveVTK=False,
+               solver_factory=OracleStepper, quiet=True)
+    assert not any(t[1] in (0.17, 0.15) for t in texts)                    # closure off: no closure lines
+    assert any(t[2].startswith("omega_nu, omega_e, omega_eps, omega_q") for t in texts)
 
 
 def test_no_output_flags_means_one_batch(tmp_path, monkeypatch):

@@ -335,6 +335,42 @@ def test_reynolds_sweep_datagen(tmp_path):
         assert its2[i] == o.nsteps, (re, its2[i], o.nsteps)
         assert np.array_equal(f2[i], o.fin) and np.array_equal(u2[i], o.u), re
     assert len(set(its2.tolist())) > 1 and its2.min() < 6000
+    # the same criterion evaluated on lbm_mean_u -- mean(u) reduced on the device in double, B doubles per check
+    # over PCIe instead of B fields.  Same stop iteration as the host criterion for every lattice of this sweep (the two means
+    # differ by ~1e-9 relative, the decisive differences here are ~1e-3 of the tolerance away), same final populations.
+    _, f3, u3, _, its3 = generate(Re, xsize=48, ysize=48, maxIt=6000, Pinterval=100, tolerance=2e-3, concurrent=4, save=False, quiet=True,
+                                  convergence="device")
+    assert np.array_equal(its3, its2) and np.array_equal(f3, f2) and np.array_equal(u3, u2)
+
+
+def test_mean_u_and_tau_exports():
+    """lbm_mean_u == mean of the u that lbm_get_fields returns (accumulated in double, run-to-run identical), for a single
+    lattice, a batch and after single-step and multi-step units; lbm_get_tau == taus_g of the closure recomputed from the
+    oracle's state (MRT_GPU.py:385-387), 1 / omega without the closure."""
+    with CavitySolver(132, 99, 5000.0, RT="SRT", dtype=np.float32, turb=1, kernel="tb") as s:
+        o = CavityOracleC(132, 99, 5000.0, semantics="mrt_gpu", collision="SRT", dtype=np.float32, turb=1)
+        for n in (1, 7, 1, 13):
+            s.step(n)
+            u, rho = s.get_fields()
+            m = s.mean_u()
+            assert m == s.mean_u()
+            assert abs(m - float(np.mean(u.astype(np.float64)))) < 1e-12
+            # the oracle one step behind holds the state (fin) and history (feq, rho of the step before) the last iteration started from
+            o.step(s.steps_done - 1 - o.nsteps)
+            f = o.fin.astype(np.float64)
+            q = (f[5] - f[6] + f[7] - f[8]) - (o.feq[5].astype(np.float64) - o.feq[6] + o.feq[7] - o.feq[8])
+            tau0 = 1.0 / s.relax["omega"]
+            tau = 0.5 * (tau0 + np.sqrt(tau0 * tau0 + 18 * 1.4142 * 0.025 * np.abs(q) / o.rho.astype(np.float64)))
+            got = s.get_tau(out_dtype=np.float64)
+            assert np.abs(got - tau).max() < 2e-6 * tau0, n
+            assert got.min() >= tau0 * (1 - 1e-6) and got.max() > tau0 * (1 + 1e-4)
+    with CavityBatch(64, 64, [100.0, 1000.0, 5000.0], RT="MRT", dtype=np.float64) as b:
+        b.step(30)
+        u, _ = b.get_fields()
+        m = b.mean_u()
+        assert m.shape == (3,) and np.allclose(m, u.reshape(3, -1).mean(axis=1), rtol=0, atol=1e-15)
+        tau = b.get_tau()
+        assert tau.shape == (3, 64, 64) and all(np.all(tau[i] == 1.0 / b.relax_list[i]["omega"]) for i in range(3))
 
 
 @pytest.mark.parametrize("kernel", ["generic", "vec", "tb"])

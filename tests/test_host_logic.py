@@ -78,6 +78,41 @@ def test_vtr_rejects_mismatched_shapes(tmp_path, monkeypatch):
         saveToVTK((a, a, a), np.zeros((4, 4, 1)), "p", "0", (np.arange(4.), np.arange(3.), np.arange(1.)))
 
 
+def test_vtr_correct_mode_is_point_data_of_the_same_grid(tmp_path, monkeypatch):
+    """correct=True: the reference attaches X*Y values as CELL data to a grid that has (X-1)*(Y-1) cells
+    (MRT.py:91-94,606-610 vs pyevtk/hl.py:152-153); the correct mode writes the same bytes as POINT data (X*Y points)."""
+    g = np.load(os.path.join(GOLDEN, "vtr_4x3.npz"))
+    monkeypatch.chdir(tmp_path)
+    ref = g["vtr"].tobytes()
+    path = saveToVTK((g["ux"], g["uy"], g["uz"]), g["rho"], "ldc", "00001", (g["gx"], g["gy"], g["gz"]), correct=True)
+    got = open(path, "rb").read()
+    assert got != ref and len(got) == len(ref) + 2 * (len("PointData") - len("CellData"))
+    assert got.replace(b"PointData", b"CellData") == ref            # same extents, offsets and appended blocks
+    nx, ny = g["ux"].shape[:2]
+    assert b'WholeExtent="0 %d 0 %d 0 0"' % (nx - 1, ny - 1) in got   # nx * ny points = one per value
+    with pytest.raises(ValueError):                                  # a value count that does not match the points
+        saveToVTK((g["ux"][:-1], g["uy"][:-1], g["uz"][:-1]), g["rho"][:-1], "ldc", "2", (g["gx"], g["gy"], g["gz"]), correct=True)
+
+
+def test_locate_vortices_finds_two_minima_away_from_the_walls():
+    """MRT_GPU.py:764-778: the first minimum of |u|^2 outside a wall margin of X/40 cells, then the next one outside a box of
+    that half-width around the first; on a synthetic field with two known zeros (and a third, deeper one inside the wall margin)."""
+    X = Y = 200
+    off = X // 40
+    xx, yy = np.meshgrid(np.arange(X), np.arange(Y), indexing="ij")
+    c1, c2, cw = (120, 70), (40, 150), (2, 100)                      # cw sits inside the wall margin: must be ignored
+    d = lambda c: np.sqrt((xx - c[0]) ** 2.0 + (yy - c[1]) ** 2.0)  # noqa: E731
+    speed = np.minimum(np.minimum(d(c1) * 1.0, d(c2) * 1.5 + 0.01), d(cw) * 0.1) * 1e-3
+    u = np.stack([speed, np.zeros_like(speed)]).astype(np.float32)
+    loc1, loc2 = ghia.locate_vortices(u, 0.08)
+    assert loc1 == c1 and loc2 == c2
+    assert min(loc1[0], loc1[1], X - 1 - loc1[0], Y - 1 - loc1[1]) >= off
+    # a second minimum right next to the first is masked by the box around it
+    u2 = u.copy()
+    u2[0, c1[0] + 2, c1[1] + 1] = 0.0
+    assert ghia.locate_vortices(u2, 0.08)[1] == c2
+
+
 def test_partition_rows():
     assert partition_rows(4096, 1) == [(0, 4096)]
     assert partition_rows(8192, 8) == [(i * 1024, 1024) for i in range(8)]
