@@ -255,28 +255,28 @@ def main():
         # timed region divided by its launch units (with the default plan every unit is the same kernel at the same S; single
         # steps, if the step count leaves a remainder, are counted as units of their own).
         S_dom = max(units) if units else 1
-        n_dom = sum(1 for u in units if u == S_dom)
         pure = bool(units) and all(u == S_dom for u in units)
         launch_ms = ev_ms / len(units) if units else float("nan")
         min_bytes_launch = cells_rank * 2 * 9 * es
         hbm_achieved = min_bytes_launch / (launch_ms * 1e-3) / 1e9
-        kname = {"auto": "k_stepS_deep", "tb": "k_stepS_deep", "vec": "k_step_vec", "generic": "k_step_generic", "push": "k_push_collide+k_push_bc"}.get(a.kernel, a.kernel)
+        plan = solver.describe()
+        kname = plan["kernel"] if a.kernel in ("auto", "tb", "stream") and plan["kernel"] != "none" else \
+            {"vec": "k_step_vec", "generic": "k_step_generic", "push": "k_push_collide+k_push_bc"}.get(a.kernel, a.kernel)
         key = f"{a.config}:{world}:{a.kernel}:{a.arith}"
         tr = load_static("traffic.json").get(key, {})
         traffic = None
-        if tr and tr.get("steps_per_launch", S_dom) == S_dom:       # PMC bytes of this kernel at this S, from the committed profile
-            traffic = tr.get("hbm_bytes_per_launch")
-        vm = load_static("valu_mix.json").get(f"{kname}:{dtype}:{RT}:{a.arith}:S{S_dom}", {})
+        if tr and tr.get("steps_per_launch", S_dom) == S_dom and tr.get("kernel", kname) == kname:   # PMC bytes of THIS kernel at THIS S, from the
+            traffic = tr.get("hbm_bytes_per_launch")                                                 # committed profile (else null)
+        vm = load_static("valu_mix.json").get(f"{kname}:{dtype}:{RT}:{a.arith}:turb0", {})
         valu = None
-        if vm and S_dom > 1:
-            # VALU issue line: issue cycles of one workgroup's instruction stream (disassembly x measured issue cost per
-            # instruction class, tools/valu_mix.py + tools/valu_issue.hip) x workgroups per launch, over the cycles the 1024
-            # SIMDs offer during the launch at the 2.4 GHz peak clock
-            wgs = tr.get("workgroups_per_launch") or vm.get("workgroups_4096")
-            if wgs:
-                cyc = vm["issue_cycles_per_workgroup"] * wgs
-                valu = {"issue_cycles_per_launch": cyc, "frac": round(cyc / (launch_ms * 1e-3 * CLOCK_PEAK_GHZ * 1e9 * SIMDS), 4),
-                        "source": vm.get("source")}
+        if vm and plan.get("wave_updates", 0) > 0 and S_dom == plan["steps_per_launch"]:
+            # VALU issue line: (wave, level) updates of one launch (lbm_describe: rows x strips x levels, lead rows included) x the
+            # issue cycles of one update (the kernel's level loop priced per instruction class: tools/valu_mix.py with the costs
+            # measured by tools/valu_issue.hip), over the cycles the 1024 SIMDs offer during the launch at the 2.4 GHz peak clock
+            cyc = vm["issue_cycles_per_wave_update"] * plan["wave_updates"]
+            valu = {"wave_updates_per_launch": plan["wave_updates"], "issue_cycles_per_wave_update": vm["issue_cycles_per_wave_update"],
+                    "frac": round(cyc / (launch_ms * 1e-3 * CLOCK_PEAK_GHZ * 1e9 * SIMDS), 4), "peak": f"{SIMDS} SIMDs x {CLOCK_PEAK_GHZ} GHz",
+                    "source": vm.get("source")}
         roof = {"bound": "hbm", "achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(hbm_achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel": kname, "steps_per_launch": S_dom, "launches_timed": len(units), "launch_ms": round(launch_ms, 5),
@@ -293,10 +293,8 @@ def main():
                         "SURVEY 8(d)'s per-update figure is reported separately as algorithmic_GBps = 72 or 144 B x updates / time and is "
                         "not a bound; traffic = PMC FETCH_SIZE x 2 + WRITE_SIZE of the same kernel from the committed rocprofv3 profile "
                         "(static, not measured in this run)" + ("" if pure else "; the timed region mixes launch units of different length")}
-        if valu and valu["frac"] > roof["frac"] and (roof["traffic_frac_of_peak"] or 0) < valu["frac"]:
-            roof["binding"] = "valu_issue"          # (informational: the larger fraction is the nearer limit)
-        else:
-            roof["binding"] = "hbm"
+        # the nearer of the two limits (informational; `bound` / `frac` stay the HBM line the contract asks for)
+        roof["binding"] = "valu_issue" if valu and valu["frac"] > max(roof["frac"], roof["traffic_frac_of_peak"] or 0) else "hbm"
         other = {}
         if not a.no_extra and world == 1:
             try:

@@ -151,6 +151,11 @@ long long lbm_steps_done(const lbm_ctx* c);
  * whether the lattice has just been uploaded -- the same on every rank of a decomposition. */
 int lbm_next_unit(const lbm_ctx* c, int steps_left);
 
+/* The launch plan as text (for logs and for bench.py's roofline line): one line of `key=value` pairs -- kernel of the multi-step
+ * units (k_stream | k_stepS_deep | k_step2_deep | none), steps per launch, frame width, workgroups and strip rows of a launch, ...
+ * Returns the length written (truncated to len - 1), negative on a bad argument. */
+int lbm_describe(const lbm_ctx* c, char* buf, size_t len);
+
 /* --- state out --------------------------------------------------------------------- */
 /* replaces: cuda.memcpy_dtoh(fin, ftemp_g); memcpy_dtoh(rho, rho_g); memcpy_dtoh(u, u_g)
  * + transposes (MRT_GPU.py:755-760).  Synchronises.  u_host[2][nx][ny], rho_host[nx][ny]

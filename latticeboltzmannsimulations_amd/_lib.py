@@ -96,6 +96,7 @@ SIGNATURES = {
     "lbm_time_steps": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "lbm_steps_done": (ctypes.c_longlong, [_vp]),
     "lbm_next_unit": (_i, [_vp, _i]),
+    "lbm_describe": (_i, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     "lbm_get_fields": (_i, [_vp, _vp, _vp, _vp, _i]),
     "lbm_mean_u": (_i, [_vp, ctypes.POINTER(_d)]),
     "lbm_get_tau": (_i, [_vp, _vp, _i]),

@@ -1118,6 +1118,33 @@ int lbm_next_unit(const lbm_ctx* c, int steps_left) {
     return unit_steps(c, steps_left, c->raw[c->cur] != 0);
 }
 
+int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
+    if (!c || !buf || len == 0) return LBM_ERR_INVALID;
+    const char* kern = !c->use_tb ? "none" : c->stream ? "k_stream" : c->tb_steps == 2 ? "k_step2_deep" : "k_stepS_deep";
+    const int S = c->use_tb ? c->tb_steps : 1;
+    long long wgs = 0, wave_updates = 0;   // per launch of S steps: workgroups of the bulk kernel; (wave, level) updates they perform
+    const int V = 16 / c->es;
+    if (c->stream) {
+        const StreamPlan pl = plan_stream(c, S);
+        wgs = (long long)pl.nstrips * pl.nsegy;
+        const long long rows = c->geo.ny - 2 * c->tb_f;
+        wave_updates = (long long)pl.nstrips * (rows + (long long)pl.nsegy * 2 * (S - 1)) * S;
+    } else if (c->use_tb && S >= 3) {
+        const int F = c->tb_f, RV = (S - 1 + V - 1) / V, TX = (16 - 2 * RV) * V, TY = 32 - 2 * (S - 1);
+        const long long ntx = (c->geo.nx - 2 * F + TX - 1) / TX, nty = (c->geo.ny - 2 * F + TY - 1) / TY;
+        wgs = ntx * nty * c->batch;
+        long long per = 0;                 // active waves per step: rows [s - 1, 32 - (s - 1)) of 16 lanes -> (32 - 2 (s - 1)) / 4 waves
+        for (int s = 1; s <= S; ++s) per += (32 - 2 * (s - 1)) / 4 + ((32 - 2 * (s - 1)) % 4 ? 1 : 0);
+        wave_updates = wgs * per;
+    }
+    const int n = std::snprintf(buf, len, "kernel=%s steps_per_launch=%d frame=%d stream=%d vec=%d nt=%d deep_halo=%d frame_fused=%d lazy_lag=%d "
+                                "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d",
+                                kern, S, c->use_tb ? c->tb_f : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
+                                c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->geo.row != c->geo.pitch ? "rows" : "planes", wgs, wave_updates, V,
+                                is_slab(c) ? 1 : 0);
+    return n < 0 ? LBM_ERR_INVALID : (n >= (int)len ? (int)len - 1 : n);
+}
+
 int lbm_sync(lbm_ctx* c) {
     if (!c) return LBM_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->p.device));

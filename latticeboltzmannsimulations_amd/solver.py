@@ -181,6 +181,17 @@ class CavitySolver:
     def steps_done(self):
         return int(self.lib.lbm_steps_done(self._h))
 
+    def describe(self):
+        """The launch plan as a dict (lbm_describe): kernel of the multi-step units, steps per launch, frame width, ..."""
+        buf = ctypes.create_string_buffer(512)
+        if self.lib.lbm_describe(self._h, buf, len(buf)) < 0:
+            raise RuntimeError("lbm_describe failed")
+        out = {}
+        for kv in buf.value.decode().split():
+            k, v = kv.split("=", 1)
+            out[k] = int(v) if v.lstrip("-").isdigit() else v
+        return out
+
     def next_unit(self, steps_left):
         """Time steps the next launch unit of step() advances when `steps_left` remain (1 = a single step)."""
         n = int(self.lib.lbm_next_unit(self._h, int(steps_left)))
