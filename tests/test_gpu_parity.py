@@ -363,7 +363,9 @@ def test_mean_u_and_tau_exports():
             tau = 0.5 * (tau0 + np.sqrt(tau0 * tau0 + 18 * 1.4142 * 0.025 * np.abs(q) / o.rho.astype(np.float64)))
             got = s.get_tau(out_dtype=np.float64)
             assert np.abs(got - tau).max() < 2e-6 * tau0, n
-            assert got.min() >= tau0 * (1 - 1e-6) and got.max() > tau0 * (1 + 1e-4)
+            assert got.min() >= tau0 * (1 - 1e-6)
+            if s.steps_done > 5:                       # (the very first iteration starts from the equilibrium: tau = tau0 everywhere)
+                assert got.max() > tau0 * (1 + 1e-4)
     with CavityBatch(64, 64, [100.0, 1000.0, 5000.0], RT="MRT", dtype=np.float64) as b:
         b.step(30)
         u, _ = b.get_fields()
