@@ -57,8 +57,10 @@ enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange af
        LBM_FLAG_NT_ON = 16,              /* non-temporal loads / stores on (default: lattices above 192 MiB) ... */
        LBM_FLAG_NT_OFF = 32,             /* ... or off */
        LBM_FLAG_COMM_PRIORITY_OFF = 64,  /* communication stream at the compute stream's priority */
-       LBM_FLAG_EAGER_LAG = 128 };       /* every lbm_step() call ends with a single step (so that the lattice of the step before
+       LBM_FLAG_EAGER_LAG = 128,         /* every lbm_step() call ends with a single step (so that the lattice of the step before
                                             the last exists) instead of recomputing it when lbm_get_fields asks for u / rho */
+       LBM_FLAG_FRAME_BESIDE_ON = 512,   /* kernel STREAM, lone lattice: the wall frame as a kernel of its own on the second stream, beside the */
+       LBM_FLAG_FRAME_BESIDE_OFF = 1024 };/* streaming workgroups, always / never (default: when the streaming kernel variant leaves registers free) */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
  * reference bakes them into the CUDA source by '%'-formatting (MRT_GPU.py:422,531,662) and

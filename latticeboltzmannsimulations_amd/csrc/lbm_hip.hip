@@ -77,6 +77,8 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
     bool use_tb = false;        // several steps per launch (temporal blocking)
+    bool frame_beside = false;  // streaming kernel of a lone lattice: the frame passes as a kernel of their own on the second stream, BESIDE the
+                                // streaming workgroups (no LDS, ~70 VGPRs: fits next to them when the streaming kernel leaves registers)
     bool stream = false;        // ... by the strip-streaming kernel (lbm_stream.hpp: large lone lattices, up to 8 steps per launch)
     int ncu = 256;              // compute units of the device (the streaming kernel runs one workgroup per CU)
     int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel), up to eight (streaming kernel)
@@ -265,6 +267,11 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
         fp.src = (const R*)c->lat[from];
         for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
         const int F = c->tb_f, L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
+        if (c->frame_beside && !lo && !hi && c->batch == 1) {
+            hipLaunchKernelGGL((k_frame_beside<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy), dim3(BLK), 0, s, fp, c->geo, relax_of<R>(c->p), F, S,
+                               nsegx, nsegy, L);
+            return;
+        }
         hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
                            relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 + extra : 0, hi ? 1 + extra : 0, L,
                            frame_lds_fits(c, S, lo || hi, extra) ? 1 : 0);
@@ -548,7 +555,7 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
 // column strips as separate launches on separate streams was measured and lost 8 %: profiles/r01_logs/perf31.log, perf35.log.)
 int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     const bool slab = is_slab(c);
-    if (!slab && c->frame_fused && S >= 3) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
+    if (!slab && c->frame_fused && S >= 3 && !(c->stream && c->frame_beside)) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
         HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // (frame launches of an earlier unit, if any)
         int rc = launch_deep(c, c->cur, c->cur ^ 1, c->s_compute, S, true);
         if (rc) return rc;
@@ -964,10 +971,34 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         if (c->stream) {
             c->use_tb = true;
             c->tb_steps = p->tb_steps ? p->tb_steps : ST_MAX_S;
-            c->tb_f = (c->tb_steps + 1 + 3) / 4 * 4;    // F >= S + 1, a multiple of the vector width: 4 (S <= 3), 8 (S <= 7), 12
+            // Frame width F, a multiple of the vector width.  Level 1 of the streaming kernel computes the cells from F - (S - 1)
+            // inwards as plain pull-and-collide cells: with MRT_GPU.py's full streaming windows every cell but the wall cells
+            // themselves is one (in_window), so F >= S; MRT.py's truncated windows leave kept slots in the cell next to the right /
+            // bottom wall too, so F >= S + 1.
+            const int fmin = p->semantics == LBM_SEM_MRT_GPU ? 0 : 1;
+            c->tb_f = (c->tb_steps + fmin + 3) / 4 * 4;
             while (c->tb_steps > 2 && (p->nx < 2 * c->tb_f + 16 || ny_plan < 2 * c->tb_f + 16)) {   // (tiny lattices: keep an interior)
                 c->tb_steps -= 1;
-                c->tb_f = (c->tb_steps + 1 + 3) / 4 * 4;
+                c->tb_f = (c->tb_steps + fmin + 3) / 4 * 4;
+            }
+            // The wall frame of a lone lattice: inside the launch (its first workgroups; they hold a CU each for ~43 us before the
+            // streaming workgroups start) or as a kernel of its own on the second stream that runs BESIDE them.  The latter needs
+            // room next to a streaming workgroup, which takes all the LDS and four waves per SIMD: chosen when the registers of
+            // four streaming waves and one frame wave fit the 512 per SIMD lane (allocated in blocks of 8) -- the factored
+            // operators without the Smagorinsky closure -- and only in fp64, where it pays: 4096 x 4096 fast MRT 153 -> 169 GLUPS;
+            // in fp32 the frame waves slow the streaming waves by more than the 43 us they save, 367 -> 338
+            // (profiles/r02_logs/stream_ab18.log)
+            if (p->flags & LBM_FLAG_FRAME_BESIDE_ON) c->frame_beside = true;
+            else if (!(p->flags & LBM_FLAG_FRAME_BESIDE_OFF) && c->batch == 1 && c->es == 8) {
+                int rs = 1 << 20, rf = 1 << 20;
+                dispatch(c->p, [&](auto v) {
+                    using VT = decltype(v);
+                    using R = typename VT::R;
+                    hipFuncAttributes at;
+                    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_stream<R, VT::COLL, VT::SEM, VT::TURB>)) == hipSuccess) rs = at.numRegs;
+                    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_frame_beside<R, VT::COLL, VT::SEM, VT::TURB>)) == hipSuccess) rf = at.numRegs;
+                });
+                c->frame_beside = (rs + 7) / 8 * 8 * 4 + (rf + 7) / 8 * 8 <= 512;
             }
         } else {
             if (want > 5) return (delete c, bail("tb_steps 6 .. 8 need kernel = STREAM"));
@@ -994,6 +1025,12 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) c->ncu = prop.multiProcessorCount;
+    }
+    // beside the streaming kernel one frame workgroup fits on a CU: as many workgroups as CUs, not more (8192^2 fp64: 187 GLUPS
+    // with 64 cells = 512 workgroups, 201 with 128 = 256; profiles/r02_logs/stream_ab20.log)
+    if (c->frame_beside && !p->frame_seg) {
+        const long long per = 2LL * p->nx + 2LL * ((p->ny_local_min ? p->ny_local_min : p->ny_local) - 2 * c->tb_f);
+        c->frame_seg = std::max(64, (int)(((per + c->ncu - 1) / c->ncu + 7) / 8 * 8));
     }
     if ((e = hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking)) != hipSuccess) return cleanup("hipStreamCreate");
     {   // halo exchange stream at the highest priority: its (tiny) RCCL kernels must not queue behind the
@@ -1138,10 +1175,10 @@ int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
         wave_updates = wgs * per;
     }
     const int n = std::snprintf(buf, len, "kernel=%s steps_per_launch=%d frame=%d stream=%d vec=%d nt=%d deep_halo=%d frame_fused=%d lazy_lag=%d "
-                                "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d",
+                                "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d frame_beside=%d",
                                 kern, S, c->use_tb ? c->tb_f : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
                                 c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->geo.row != c->geo.pitch ? "rows" : "planes", wgs, wave_updates, V,
-                                is_slab(c) ? 1 : 0);
+                                is_slab(c) ? 1 : 0, c->frame_beside ? 1 : 0);
     return n < 0 ? LBM_ERR_INVALID : (n >= (int)len ? (int)len - 1 : n);
 }
 

@@ -190,6 +190,15 @@ __global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, R
     frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg, use_lds ? lds : nullptr);
 }
 
+// The same passes for the wall frame of a lone lattice whose bulk runs in the streaming kernel, launched on the second stream
+// to run BESIDE it: a streaming workgroup takes all of a CU's LDS and four waves per SIMD x 96 .. 128 VGPRs, which can leave room
+// for one wave per SIMD of a kernel without LDS (the passes go through the scratch lattices) and with 42 .. 91 VGPRs; lbm_create
+// compares the register counts of the two kernel variants (hipFuncGetAttributes) and chooses.
+template <typename R, int COLL, int SEM, bool TURB>
+__global__ __launch_bounds__(BLK) void k_frame_beside(FramePtrs<R> fp, Geo geo, Relax<R> w, int F, int S, int nsegx, int nsegy, int seg) {
+    frame_passes<R, COLL, SEM, TURB, BLK>(fp, 0, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg, nullptr);
+}
+
 // S = 3 .. 5 steps per launch: region of 512 vector cells = one per thread, 48 KiB of LDS.  The
 // occupancy floor of 4 waves per SIMD (<= 128 VGPRs) keeps two workgroups on a CU: the MRT / TRT + Smagorinsky variants would
 // otherwise take 132 and run one (perf22.log vs perf23.log: fp32 MRT turb 96 -> 115 GLUPS).  WIDE: region 32 vectors x 16 rows;

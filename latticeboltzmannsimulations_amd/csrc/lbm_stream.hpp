@@ -181,8 +181,8 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
     for (; done < jtot; ++done) lds_barrier();
 }
 
-// grid: [nframe frame workgroups (a lone lattice)] + nstrips * nsegy segments.  S <= ST_MAX_S steps; F = frame width (>= S + 1,
-// a multiple of the vector width); a strip's useful columns are [xs + R, xs + 64 V - R), the first strip's start at F.
+// grid: [nframe frame workgroups (a lone lattice)] + nstrips * nsegy segments.  S <= ST_MAX_S steps; F = frame width (>= S, and >= S + 1
+// with MRT.py's streaming windows; a multiple of the vector width); a strip's useful columns are [xs + R, xs + 64 V - R), the first strip's start at F.
 template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(ST_NT) void k_stream(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int S, int F, int xe, int ye,
                                                   int nstrips, int H, FramePtrs<R> fp, int nframe, int nsegx, int nsegy, int seg, int use_lds) {

@@ -44,6 +44,9 @@ def _tuning(t):
     nt = t.pop("nt", None)
     if nt is not None:
         flags |= L.LBM_FLAG_NT_ON if nt else L.LBM_FLAG_NT_OFF
+    fb = t.pop("frame_beside", None)
+    if fb is not None:
+        flags |= L.LBM_FLAG_FRAME_BESIDE_ON if fb else L.LBM_FLAG_FRAME_BESIDE_OFF
     if t:
         raise ValueError(f"unknown tuning switches {sorted(t)}")
     return tb, seg, flags
@@ -69,7 +72,7 @@ class CavitySolver:
                    derived from it, so that neighbours run the same exchange protocol
     tuning       : A/B switches of the launch plan, none of which changes a result: tb_steps (2..5 steps per launch),
                    frame_seg, and the boolean flags deep_halo, frame_fused, frame_fused_batch, frame_lds, nt, comm_priority,
-                   eager_lag (lbm_params.tb_steps / frame_seg / flags)
+                   eager_lag, frame_beside (lbm_params.tb_steps / frame_seg / flags)
     """
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,
