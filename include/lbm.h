@@ -60,7 +60,8 @@ enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange af
        LBM_FLAG_EAGER_LAG = 128,         /* every lbm_step() call ends with a single step (so that the lattice of the step before
                                             the last exists) instead of recomputing it when lbm_get_fields asks for u / rho */
        LBM_FLAG_FRAME_BESIDE_ON = 512,   /* kernel STREAM, lone lattice: the wall frame as a kernel of its own on the second stream, beside the */
-       LBM_FLAG_FRAME_BESIDE_OFF = 1024 };/* streaming workgroups, always / never (default: when the streaming kernel variant leaves registers free) */
+       LBM_FLAG_FRAME_BESIDE_OFF = 1024, /* streaming workgroups, always / never (default: when the streaming kernel variant leaves registers free) */
+       LBM_FLAG_FRAME_NARROW = 2048 };   /* frame passes that go through the scratch lattices: workgroups of 256 threads instead of 1024 */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
  * reference bakes them into the CUDA source by '%'-formatting (MRT_GPU.py:422,531,662) and
@@ -217,7 +218,10 @@ int lbm_step_unit(lbm_ctx* c, int unit_steps);
  * steps, the S complete rows next to each interface in one message per side (MRT_GPU semantics).
  * Rank r must hold the r-th slab from the lid (rank 0: y0 = 0, last rank: y0 + ny_local = ny).  lbm_comm_init compares
  * the launch plan (steps per launch, frame width, deep halo, row pitch, planes) with both neighbours and fails with
- * LBM_ERR_STATE if they differ (pass the same lbm_params.ny_local_min on every rank). */
+ * LBM_ERR_STATE if they differ (pass the same lbm_params.ny_local_min on every rank).
+ * RCCL is bound with dlopen("librccl.so.1") on the first lbm_comm_* call and the copy already mapped in the process is the one
+ * taken: a process that also loads a framework with a bundled RCCL (PyTorch) must load it BEFORE that call, or it ends up with
+ * two RCCLs and aborts at exit (the Python host does this itself, solver._one_rccl). */
 int lbm_comm_unique_id(void* uid_out128);
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128);
 /* Diagnostic for one-GPU machines: attaches a ONE-rank RCCL communicator and makes the slab its own

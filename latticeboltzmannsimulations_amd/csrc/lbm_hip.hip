@@ -77,6 +77,7 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
     bool use_tb = false;        // several steps per launch (temporal blocking)
+    bool frame_wide = true;     // frame passes through the scratch lattices: workgroups of 1024 threads (A/B: LBM_FLAG_FRAME_NARROW)
     bool frame_beside = false;  // streaming kernel of a lone lattice: the frame passes as a kernel of their own on the second stream, BESIDE the
                                 // streaming workgroups (no LDS, ~70 VGPRs: fits next to them when the streaming kernel leaves registers)
     bool stream = false;        // ... by the strip-streaming kernel (lbm_stream.hpp: large lone lattices, up to 8 steps per launch)
@@ -254,7 +255,7 @@ bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows, int extra = 0, long
     if (!c->frame_lds) return false;
     const int F = c->tb_f, L = c->frame_seg, m = S - 1, np = c->p.turb ? Q + 2 : Q;
     const long long row_strip = (long long)(L + 2 * m + 2) * (F + m + (deep_rows ? m + extra : 0) + 2);
-    const long long col_strip = (long long)(F + m + 2) * (L + 2 * m + 2);
+    const long long col_strip = (long long)(F + m + 2) * (L + 2 * m + extra + 2);
     return 2 * np * std::max(row_strip, col_strip) * c->es <= budget;
 }
 
@@ -272,9 +273,13 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
                                nsegx, nsegy, L);
             return;
         }
-        hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
-                           relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 + extra : 0, hi ? 1 + extra : 0, L,
-                           frame_lds_fits(c, S, lo || hi, extra) ? 1 : 0);
+        const bool in_lds = frame_lds_fits(c, S, lo || hi, extra);
+        if (!in_lds && c->frame_wide)
+            hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB, 1024>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(1024), 0, s, fp, c->geo,
+                               relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 + extra : 0, hi ? 1 + extra : 0, L, 0);
+        else
+            hipLaunchKernelGGL((k_frame_multi<R, VT::COLL, VT::SEM, VT::TURB, BLK>), dim3(2 * nsegx + 2 * nsegy, c->batch), dim3(BLK), 0, s, fp, c->geo,
+                               relax_of<R>(c->p), batch_of<R>(c), F, S, nsegx, nsegy, lo ? 1 + extra : 0, hi ? 1 + extra : 0, L, in_lds ? 1 : 0);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -313,7 +318,34 @@ int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_
         const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
         hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(nframe + pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s,
                            (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, F, xe, ye, pl.nstrips, pl.H,
-                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, ST_LDS_BYTES) ? 1 : 0);
+                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, ST_LDS_BYTES) ? 1 : 0, 0, 0, 0);
+    });
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
+// The edge launch of a slab's unit under the streaming kernel: everything but the bulk rows [F, ny - F) x [F, nx - F) -- the wall
+// frame (the column strips over the slab's whole height, the row strip of a lid / bottom wall this slab holds) by the frame
+// workgroups and, on each side with a neighbour, the F rows next to the interface between the column strips as a short
+// streaming segment that starts in the neighbour's rows of the deep halo.  It writes every row the next exchange sends.
+// extra: rows of the neighbours' side owned on top (1 for the lagged lattice, see frame_passes).
+int launch_stream_edges(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool lo, bool hi, int extra) {
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
+        const int F = c->tb_f, xe = c->geo.nx - F, ye = c->geo.ny - F;
+        const StreamPlan pl = plan_stream(c, S);
+        FramePtrs<R> fp;
+        fp.src = (const R*)c->lat[from];
+        for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+        const int bands = (lo ? 1 : 0) | (hi ? 2 : 0);
+        const int ybeg = lo ? -extra : F, yend = hi ? c->geo.ny + extra : c->geo.ny - F;
+        const int L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (yend - ybeg + L - 1) / L;
+        const int nframe = 2 * nsegx + 2 * nsegy;
+        hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(nframe + pl.nstrips * ((lo ? 1 : 0) + (hi ? 1 : 0))), dim3(ST_NT), 0, s,
+                           (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, F, xe, ye, pl.nstrips, pl.H,
+                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, extra, ST_LDS_BYTES) ? 1 : 0, lo ? 1 + extra : 0,
+                           hi ? 1 + extra : 0, bands);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -575,7 +607,10 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // this unit's tile kernel needs the previous unit's frame
     int from = a;
     const bool has_lo = has_neighbour(c, LBM_SIDE_LOW), has_hi = has_neighbour(c, LBM_SIDE_HIGH);
-    if (c->frame_fused && S >= 3 && (!slab || deep)) {
+    if (c->frame_fused && S >= 3 && c->stream && deep) {
+        rc = launch_stream_edges(c, a, b, c->s_comm, S, has_lo, has_hi, 0);
+        if (rc) return rc;
+    } else if (c->frame_fused && S >= 3 && (!slab || deep)) {
         rc = launch_frame_multi(c, a, b, S, c->s_comm, deep && has_lo, deep && has_hi);
         if (rc) return rc;
     } else
@@ -655,7 +690,8 @@ int prev_lattice(lbm_ctx* c, int* which) {
             const bool lo = has_neighbour(c, LBM_SIDE_LOW), hi = has_neighbour(c, LBM_SIDE_HIGH);
             // one row more than a launch unit computes: the field export pulls the slab's first / last row from the first ghost
             // rows of this lattice (the unit received S = k + 1 rows per side: enough)
-            if (c->frame_fused) rc = launch_frame_multi(c, from, LAT_LAG, k, c->s_compute, lo, hi, 1);
+            if (c->frame_fused && c->stream && c->deep_halo) rc = launch_stream_edges(c, from, LAT_LAG, c->s_compute, k, lo, hi, 1);
+            else if (c->frame_fused) rc = launch_frame_multi(c, from, LAT_LAG, k, c->s_compute, lo, hi, 1);
             else {
                 rc = LBM_OK;
                 int f = from;
@@ -963,11 +999,18 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const bool deep_ok = p->nx >= 64 && ny_plan >= 64;
         // The strip-streaming kernel (lbm_stream.hpp): one workgroup per CU marches down a strip of 240 fp32 / 112 fp64 useful
         // columns, up to 8 steps per launch, no rim in y.  It needs tall segments to amortise its pipeline fill, i.e. a large
-        // lattice: AUTO takes it for lone lattices from 3072^2 cells (profiles/r02_logs/stream_ab.log); kernel = STREAM forces it.
-        const bool can_stream = can_tb && deep_ok && c->batch == 1 && !slab;
+        // lattice (AUTO: below); kernel = STREAM forces it.  Between slabs the unit is an edge launch + a bulk launch (multi_step).
+        const bool can_stream = can_tb && deep_ok && c->batch == 1;
         if (p->kernel == LBM_KERNEL_STREAM && !can_stream)
-            return (delete c, bail("kernel = STREAM takes one whole lattice with nx % (16 / sizeof(real)) == 0, nx >= 64, ny >= 64"));
-        c->stream = can_stream && (p->kernel == LBM_KERNEL_STREAM || (p->kernel == LBM_KERNEL_AUTO && (long long)p->nx * ny_plan >= 3072LL * 3072));
+            return (delete c, bail("kernel = STREAM takes one lattice (no batch) with nx % (16 / sizeof(real)) == 0, nx >= 64, ny_local >= 64 (on every rank)"));
+        // AUTO (profiles/r02_logs/stream_ab3.log, slab_loopback5.log; fast MRT, GLUPS stream / tile): lone 2048^2 219 / 238, 4096 x 1024 229 /
+        // 240, 4096 x 2048 296 / 268, 3072^2 306 / 274, fp64 8192 x 1024 157 / 129 -> from 8 Mi cells.  A slab (its tile-kernel
+        // unit is bound by the chain exchange -> frame passes -> exchange, the streaming unit is not): 4096 x 512 143 / 139,
+        // 2048^2 200 / 185, 4096 x 1024 247 / 181, 4096 x 2048 280 / 233, fp64 8192 x 1024 133 / 117 -> from 4 Mi cells.  Lattices
+        // narrower than 2048 (few strips, not measured) keep the earlier 3072^2 rule.
+        const long long cells_plan = (long long)p->nx * ny_plan;
+        const bool stream_pays = p->nx >= 2048 ? cells_plan >= ((slab ? 4LL : 8LL) << 20) : cells_plan >= 3072LL * 3072;
+        c->stream = can_stream && (p->kernel == LBM_KERNEL_STREAM || (p->kernel == LBM_KERNEL_AUTO && stream_pays));
         if (c->stream) {
             c->use_tb = true;
             c->tb_steps = p->tb_steps ? p->tb_steps : ST_MAX_S;
@@ -1017,6 +1060,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         const long long cells1 = (long long)p->nx * ny_plan;
         c->frame_seg = p->frame_seg ? p->frame_seg : (cells1 <= 512LL * 512 ? 16 : (cells1 <= 1024LL * 1024 ? 32 : 64));
         c->frame_lds = !(p->flags & LBM_FLAG_NO_FRAME_LDS);
+        c->frame_wide = !(p->flags & LBM_FLAG_FRAME_NARROW);
         c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_DEEP_HALO);
         c->use_nt = (p->flags & LBM_FLAG_NT_ON) ? true : (p->flags & LBM_FLAG_NT_OFF) ? false : (bytes > ((size_t)192 << 20));
         c->lazy_lag = !(p->flags & LBM_FLAG_EAGER_LAG);

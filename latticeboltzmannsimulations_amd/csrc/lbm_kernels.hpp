@@ -114,21 +114,25 @@ constexpr int FRAME_LDS_BYTES = 48 * 1024;
 
 template <typename R, int COLL, int SEM, bool TURB, int NT>
 __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long boff, const Geo& geo, const Relax<R>& w, int F, int S,
-                                             int nsegx, int nsegy, int lo, int hi, int b, int FR_L, R* lds) {
+                                             int nsegx, int nsegy, int lo, int hi, int b, int FR_L, R* lds, int bands = 0) {
     // lo / hi: 0 = no neighbour on that side; e + 1 = a neighbour whose rows lie in the ghost rows, and the row strips own e of
     // them (e = 0: a launch unit; e = 1: the recomputation of the lattice of the step before the last, whose first ghost rows
     // the field export pulls from)
     const int elo = lo > 0 ? lo - 1 : 0, ehi = hi > 0 ? hi - 1 : 0;
+    // bands (bit 0: rows below F, bit 1: rows from ny - F): the streaming kernel computes that row strip between the column
+    // strips itself (as a short segment, k_stream), so the strip has no workgroups here and the column strips run to the slab's
+    // edge (and e rows beyond) on that side
     int x0, x1, y0, y1;   // owned rectangle [x0, x1) x [y0, y1)
     if (b < 2 * nsegx) {
         const int seg = b % nsegx;
         x0 = seg * FR_L; x1 = min(geo.nx, x0 + FR_L);
-        if (b < nsegx) { y0 = -elo; y1 = F; }
-        else { y0 = geo.ny - F; y1 = geo.ny + ehi; }
+        if (b < nsegx) { if (bands & 1) return; y0 = -elo; y1 = F; }
+        else { if (bands & 2) return; y0 = geo.ny - F; y1 = geo.ny + ehi; }
     } else {
         b -= 2 * nsegx;
         const int seg = b % nsegy;
-        y0 = F + seg * FR_L; y1 = min(geo.ny - F, y0 + FR_L);
+        const int ybeg = (bands & 1) ? -elo : F, yend = (bands & 2) ? geo.ny + ehi : geo.ny - F;
+        y0 = ybeg + seg * FR_L; y1 = min(yend, y0 + FR_L);
         x0 = b < nsegy ? 0 : geo.nx - F; x1 = x0 + F;
     }
     if (lds) {
@@ -181,13 +185,16 @@ __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long b
     }
 }
 
-template <typename R, int COLL, int SEM, bool TURB>
-__global__ __launch_bounds__(BLK) void k_frame_multi(FramePtrs<R> fp, Geo geo, Relax<R> w, Batch<R> bt, int F, int S, int nsegx, int nsegy,
-                                                     int lo, int hi, int seg, int use_lds) {
+// NT threads per workgroup: 256, or 1024 for the passes of a slab that go through the scratch lattices (a pass is then one sweep of
+// the workgroup instead of four or five dependent round trips to L2: the frame kernel is on the critical path exchange -> frame
+// -> exchange of a slab, profiles/r02_logs/slab_loopback2.log)
+template <typename R, int COLL, int SEM, bool TURB, int NT>
+__global__ __launch_bounds__(NT) void k_frame_multi(FramePtrs<R> fp, Geo geo, Relax<R> w, Batch<R> bt, int F, int S, int nsegx, int nsegy,
+                                                    int lo, int hi, int seg, int use_lds) {
     __shared__ __align__(16) R lds[FRAME_LDS_BYTES / sizeof(R)];
     long long boff = 0;
     if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
-    frame_passes<R, COLL, SEM, TURB, BLK>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg, use_lds ? lds : nullptr);
+    frame_passes<R, COLL, SEM, TURB, NT>(fp, boff, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg, use_lds ? lds : nullptr);
 }
 
 // The same passes for the wall frame of a lone lattice whose bulk runs in the streaming kernel, launched on the second stream

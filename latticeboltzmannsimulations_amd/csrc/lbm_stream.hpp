@@ -185,10 +185,11 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
 // with MRT.py's streaming windows; a multiple of the vector width); a strip's useful columns are [xs + R, xs + 64 V - R), the first strip's start at F.
 template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(ST_NT) void k_stream(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int S, int F, int xe, int ye,
-                                                  int nstrips, int H, FramePtrs<R> fp, int nframe, int nsegx, int nsegy, int seg, int use_lds) {
+                                                  int nstrips, int H, FramePtrs<R> fp, int nframe, int nsegx, int nsegy, int seg, int use_lds,
+                                                  int lo, int hi, int bands) {
     __shared__ __align__(16) R lds[ST_LDS_BYTES / sizeof(R)];
     if ((int)blockIdx.x < nframe) {
-        frame_passes<R, COLL, SEM, TURB, ST_NT>(fp, 0, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg, use_lds ? lds : nullptr);
+        frame_passes<R, COLL, SEM, TURB, ST_NT>(fp, 0, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg, use_lds ? lds : nullptr, bands);
         return;
     }
     constexpr int V = 16 / (int)sizeof(R);
@@ -196,7 +197,17 @@ __global__ __launch_bounds__(ST_NT) void k_stream(const R* __restrict__ src, R* 
     const int strip = b % nstrips, sy = b / nstrips;
     const int R_ = stream_rim(S, V);
     const int xs = F - R_ + strip * (64 * V - 2 * R_);
-    const int ya = F + sy * H, yb = min(ye, ya + H);
+    int ya, yb;
+    if (bands) {
+        // The edge rows of a slab (the launch that goes before the bulk launch of a unit, see multi_step): the F rows next to an
+        // interface are a segment of their own, whose pipeline starts S - 1 rows inside the neighbour's rows of the deep halo
+        // (ghost rows); lo / hi = e + 1: e rows of the neighbour's side are owned on top (the lagged lattice, frame_passes).
+        const bool top = (bands & 1) && sy == 0;
+        if (top) { ya = -(lo > 0 ? lo - 1 : 0); yb = F; }
+        else { ya = geo.ny - F; yb = geo.ny + (hi > 0 ? hi - 1 : 0); }
+    } else {
+        ya = F + sy * H; yb = min(ye, ya + H);
+    }
     if (ya >= yb) return;
     stream_segment<R, COLL, TURB>(src, dst, geo, w, lds, S, xs, ya, yb, xe);
 }
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(ST_NT) void k_stream(const R* __restrict__ src, R* 
 #endif
 #define LBM_STREAM_ONE(R, COLL, SEM, TURB)                                                                               \
     LBM_STREAM_EXTERN template __global__ void k_stream<R, COLL, SEM, TURB>(const R* __restrict__, R* __restrict__, Geo, Relax<R>, int, int, int, int, \
-                                                                          int, int, FramePtrs<R>, int, int, int, int, int);
+                                                                          int, int, FramePtrs<R>, int, int, int, int, int, int, int, int);
 #define LBM_STREAM_ALL(R)                                                                                                \
     LBM_STREAM_ONE(R, C_SRT, SEM_GPU, false) LBM_STREAM_ONE(R, C_TRT, SEM_GPU, false) LBM_STREAM_ONE(R, C_MRT, SEM_GPU, false)          \
     LBM_STREAM_ONE(R, C_MRT_FAST, SEM_GPU, false) LBM_STREAM_ONE(R, C_SRT_FAST, SEM_GPU, false) LBM_STREAM_ONE(R, C_TRT_FAST, SEM_GPU, false) \

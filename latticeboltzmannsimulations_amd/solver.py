@@ -33,7 +33,7 @@ def _tuning(t):
     t = dict(t or {})
     tb, seg, flags = int(t.pop("tb_steps", 0) or 0), int(t.pop("frame_seg", 0) or 0), 0
     off = {"deep_halo": L.LBM_FLAG_NO_DEEP_HALO, "frame_fused": L.LBM_FLAG_FRAME_UNFUSED, "frame_lds": L.LBM_FLAG_NO_FRAME_LDS,
-           "comm_priority": L.LBM_FLAG_COMM_PRIORITY_OFF}
+           "comm_priority": L.LBM_FLAG_COMM_PRIORITY_OFF, "frame_wide": L.LBM_FLAG_FRAME_NARROW}
     on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG}
     for k, bit in off.items():
         if not t.pop(k, True):
@@ -72,7 +72,7 @@ class CavitySolver:
                    derived from it, so that neighbours run the same exchange protocol
     tuning       : A/B switches of the launch plan, none of which changes a result: tb_steps (2..5 steps per launch),
                    frame_seg, and the boolean flags deep_halo, frame_fused, frame_fused_batch, frame_lds, nt, comm_priority,
-                   eager_lag, frame_beside (lbm_params.tb_steps / frame_seg / flags)
+                   eager_lag, frame_beside, frame_wide (lbm_params.tb_steps / frame_seg / flags)
     """
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,
@@ -297,11 +297,13 @@ class CavitySolver:
         self._check(self.lib.lbm_step_unit(self._h, int(unit_steps)), "lbm_step_unit")
 
     def comm_init(self, nranks, rank, uid_bytes):
+        _one_rccl()
         buf = ctypes.create_string_buffer(bytes(uid_bytes), 128)
         self._check(self.lib.lbm_comm_init(self._h, int(nranks), int(rank), buf), "lbm_comm_init")
 
     def comm_loopback(self):
         """Diagnostic: run lbm_step's RCCL exchange path on one GPU (the slab is its own periodic neighbour)."""
+        _one_rccl()
         self._check(self.lib.lbm_comm_loopback(self._h), "lbm_comm_loopback")
 
     def copy_bandwidth(self, nbytes=1 << 30, iters=10):
@@ -338,7 +340,19 @@ def _npz(path):
     return path if path.endswith(".npz") else path + ".npz"
 
 
+def _one_rccl():
+    """One RCCL per process.  The library binds RCCL with dlopen on the first lbm_comm_* call and takes the copy that is already
+    mapped; PyTorch ships its own librccl.so and maps it when torch is imported.  If torch came AFTER the library had mapped
+    /opt/rocm's, the process would hold two RCCLs and abort in their exit handlers ("double free or corruption", measured:
+    tools/probes/order_test.py) -- so where torch is installed it is imported before the first RCCL call."""
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def comm_unique_id():
+    _one_rccl()
     buf = ctypes.create_string_buffer(128)
     if L.lib().lbm_comm_unique_id(buf) != 0:
         raise RuntimeError("lbm_comm_unique_id failed")

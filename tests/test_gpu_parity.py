@@ -634,8 +634,8 @@ def test_config_c5_16384_fp32_re5000_slabs():
     """BASELINE.json configs[4] (and the edge case 'maximum sizes'): 16384 x 16384, Re = 5000, fp32 = 268 M cells, element
     offsets beyond 2^31 in the [y][k][x] layout (9.7 GB per lattice), cut into 8 slabs of 16384 x 2048 -- the per-GPU share of
     the weak-scaling series, all 8 resident on the one device.  A smooth non-trivial state advanced 12 steps as ONE lattice
-    (arith = fast as benched: raw step, five-step launches, single step) must equal, bit for bit, the same state advanced by
-    the 8 slabs through the multi-step launch units with deep halos; the first 3 steps also against the C oracle's
+    (arith = fast as benched: raw step, eight-step launches of the streaming kernel, the rest) must equal, bit for bit, the same
+    state advanced by the 8 slabs through the multi-step launch units with deep halos (edge launch + bulk launch per unit); the first 3 steps also against the C oracle's
     reference-order arithmetic within the fast form's tolerance."""
     n, steps, nslabs = 16384, 12, 8
     x = np.arange(n, dtype=np.float32)
@@ -655,7 +655,7 @@ def test_config_c5_16384_fp32_re5000_slabs():
     for sl in slabs:
         sl.set_state(fin0)
     LocalSlabs(slabs).step(steps)
-    assert slabs[0].ny_local == 2048 and slabs[1].next_unit(100) == 5
+    assert slabs[0].ny_local == 2048 and slabs[1].next_unit(100) == 8    # (the streaming kernel, as benched)
     u = np.zeros_like(u1); rho = np.zeros_like(r1); fin = np.zeros_like(f1)
     for sl in slabs:
         sl.get_fields(u=u, rho=rho, fin=fin)
@@ -873,7 +873,7 @@ def test_rccl_single_rank_communicator_is_transparent():
 
 
 @pytest.mark.parametrize("deep", [True, False])
-@pytest.mark.parametrize("kernel,layout", [("auto", "rows"), ("tb", "rows"), ("tb", "planes")])
+@pytest.mark.parametrize("kernel,layout", [("auto", "rows"), ("tb", "rows"), ("tb", "planes"), ("stream", "rows"), ("stream", "planes")])
 @pytest.mark.parametrize("dtype,coll,turb,arith", [(np.float32, "MRT", 0, "strict"), (np.float64, "SRT", 1, "strict"),
                                                    (np.float32, "MRT", 0, "fast"), (np.float32, "TRT", 1, "strict")])
 def test_rccl_exchange_path_in_loopback(dtype, coll, turb, arith, kernel, layout, deep):
@@ -882,6 +882,8 @@ def test_rccl_exchange_path_in_loopback(dtype, coll, turb, arith, kernel, layout
     result: the same slab stepped with the externally driven API and the same wrap done through host buffers.
     kernel='tb': multi-step launches between slabs -- one deep exchange per launch (the default: the frame
     passes recompute a shrinking band of the neighbour's rows) or one one-row exchange per pass (tuning deep_halo=False).
+    kernel='stream': units of 8 steps; the rows next to the interfaces are short segments of the streaming kernel that start in
+    the deep halo (the edge launch of a unit), the column strips of the wall frame run the slab's whole height.
     u / rho are read after calls that end in a multi-step unit (recomputed from the unit's deep halo) and in a single step."""
     from latticeboltzmannsimulations_amd.slab import LOW, HIGH
     nx, NY, rows = 512, 300, (100, 96)
@@ -917,13 +919,15 @@ SLAB_CASES = [(np.float32, "MRT", 0, "strict"), (np.float32, "MRT", 0, "fast"), 
               (np.float64, "MRT", 0, "strict"), (np.float64, "MRT", 0, "fast")]
 
 
+@pytest.mark.parametrize("kernel", ["tb", "stream"])
 @pytest.mark.parametrize("nslabs", [2, 3, 8])
 @pytest.mark.parametrize("dtype,coll,turb,arith", SLAB_CASES)
-def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, arith, nslabs):
+def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, arith, nslabs, kernel):
     """What every rank of a decomposition runs between its RCCL calls -- first slab (lid, one neighbour below), middle slabs,
     last slab (bottom wall): launch units of S steps, each preceded by the exchange of the S complete rows next to every
     interface (lbm_halo_export_rows -> lbm_halo_import_rows) and run by lbm_step_unit = lbm_step's own multi-step launch
-    sequence (frame passes that recompute a shrinking band of the neighbour's rows + tile kernel, two streams).  Uneven slab
+    sequence (frame passes that recompute a shrinking band of the neighbour's rows + tile kernel, two streams; kernel = stream:
+    edge launch -- column strips + the interface rows as segments of the streaming kernel -- + bulk launch).  Uneven slab
     heights, several calls whose lengths leave every remainder, fields read after every call (one-step lag recomputed from
     the deep halo on slabs).  Expected: the undivided lattice, bit for bit (and the C oracle for strict arithmetic)."""
     nx, ny = 512, 75 * 8 + 5
@@ -932,7 +936,7 @@ def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, 
     mr = min(n for _, n in parts)
     o = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision=coll, dtype=dtype, turb=turb) if arith == "strict" else None
     one = CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel="vec")
-    slabs = [CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel="tb", rows=r, min_rows=mr) for r in parts]
+    slabs = [CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel=kernel, rows=r, min_rows=mr) for r in parts]
     assert slabs[0].next_unit(1) == 1                                       # raw lattice: a single step first
     drv = LocalSlabs(slabs)
     units = set()
@@ -947,7 +951,7 @@ def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, 
         if o is not None:
             o.step(n)
             assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho), n
-    assert max(units) >= 3, units                                           # the multi-step path really ran
+    assert max(units) >= (8 if kernel == "stream" else 3), units            # the multi-step path really ran
     means = [sl.mean_u() * sl.ny_local for sl in slabs]
     assert abs(sum(means) / ny - one.mean_u()) < 1e-12
     for sl in slabs:
