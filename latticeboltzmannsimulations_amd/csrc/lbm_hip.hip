@@ -61,7 +61,7 @@ struct lbm_ctx {
     bool lag_valid = false;
     bool lazy_lag = true;       // (LBM_FLAG_EAGER_LAG: every lbm_step call ends with a single step instead)
     hipStream_t s_compute = nullptr, s_comm = nullptr;
-    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr, ev_go = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     void* stage = nullptr;
     size_t stage_bytes = 0;
     double* red_dev = nullptr;  // lbm_mean_u: partial sums + results
@@ -77,6 +77,7 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
     bool use_tb = false;        // several steps per launch (temporal blocking)
+    bool edge_first = true;     // streaming kernel between slabs: release the bulk launch behind the edge launch (A/B: LBM_FLAG_NO_EDGE_FIRST)
     bool frame_wide = true;     // frame passes through the scratch lattices: workgroups of 1024 threads (A/B: LBM_FLAG_FRAME_NARROW)
     bool frame_beside = false;  // streaming kernel of a lone lattice: the frame passes as a kernel of their own on the second stream, BESIDE the
                                 // streaming workgroups (no LDS, ~70 VGPRs: fits next to them when the streaming kernel leaves registers)
@@ -608,6 +609,18 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     int from = a;
     const bool has_lo = has_neighbour(c, LBM_SIDE_LOW), has_hi = has_neighbour(c, LBM_SIDE_HIGH);
     if (c->frame_fused && S >= 3 && c->stream && deep) {
+        // The streaming kernel between slabs: the edge launch (interface rows + column strips, everything the next exchange sends)
+        // here, the bulk launch below.  Both become ready when the previous bulk launch ends, and the bulk launch -- one
+        // workgroup per CU for its whole run -- must not take the CUs first: the edge workgroups would run last, and the next
+        // exchange after them, in the open.  So the bulk launch is released from THIS stream, one cross-stream hop behind the
+        // edge launch -- when the bulk launch runs more than one round of workgroups (16384 x 2048 fp32 slab in loopback 319 -> 359
+        // GLUPS, 8192 x 1024 fp64 133 -> 142); a one-round launch does not gain and a short one loses (4096 x 4096 355 -> 351,
+        // 4096 x 1024 249 -> 205: profiles/r02_logs/slab_loopback7.log).
+        const StreamPlan pl = plan_stream(c, S);
+        if (c->edge_first && (long long)pl.nstrips * pl.nsegy > c->ncu) {
+            HIP_TRY(c, hipEventRecord(c->ev_go, c->s_comm));
+            HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_go, 0));
+        }
         rc = launch_stream_edges(c, a, b, c->s_comm, S, has_lo, has_hi, 0);
         if (rc) return rc;
     } else if (c->frame_fused && S >= 3 && (!slab || deep)) {
@@ -1061,6 +1074,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->frame_seg = p->frame_seg ? p->frame_seg : (cells1 <= 512LL * 512 ? 16 : (cells1 <= 1024LL * 1024 ? 32 : 64));
         c->frame_lds = !(p->flags & LBM_FLAG_NO_FRAME_LDS);
         c->frame_wide = !(p->flags & LBM_FLAG_FRAME_NARROW);
+        c->edge_first = !(p->flags & LBM_FLAG_NO_EDGE_FIRST);
         c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_DEEP_HALO);
         c->use_nt = (p->flags & LBM_FLAG_NT_ON) ? true : (p->flags & LBM_FLAG_NT_OFF) ? false : (bytes > ((size_t)192 << 20));
         c->lazy_lag = !(p->flags & LBM_FLAG_EAGER_LAG);
@@ -1087,6 +1101,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
     // scratch lattices of the frame passes: one per pass but the last (the fused frame kernel), at least the ping-pong pair
@@ -1119,6 +1134,7 @@ void lbm_destroy(lbm_ctx* c) {
     if (c->ev_edges) (void)hipEventDestroy(c->ev_edges);
     if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
     if (c->ev_int) (void)hipEventDestroy(c->ev_int);
+    if (c->ev_go) (void)hipEventDestroy(c->ev_go);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
