@@ -220,9 +220,9 @@ int lbm_step_unit(lbm_ctx* c, int unit_steps);
  * Rank r must hold the r-th slab from the lid (rank 0: y0 = 0, last rank: y0 + ny_local = ny).  lbm_comm_init compares
  * the launch plan (steps per launch, frame width, deep halo, row pitch, planes) with both neighbours and fails with
  * LBM_ERR_STATE if they differ (pass the same lbm_params.ny_local_min on every rank).
- * RCCL is bound with dlopen("librccl.so.1") on the first lbm_comm_* call and the copy already mapped in the process is the one
- * taken: a process that also loads a framework with a bundled RCCL (PyTorch) must load it BEFORE that call, or it ends up with
- * two RCCLs and aborts at exit (the Python host does this itself, solver._one_rccl). */
+ * RCCL is bound with dlopen on the first lbm_comm_* call and the copy already mapped in the process is the one taken.  A process
+ * that also loads PyTorch must import it BEFORE that call: created a communicator first and imported torch afterwards, it aborts in
+ * the exit handlers (the Python host takes care of the order itself, solver._one_rccl). */
 int lbm_comm_unique_id(void* uid_out128);
 int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128);
 /* Diagnostic for one-GPU machines: attaches a ONE-rank RCCL communicator and makes the slab its own

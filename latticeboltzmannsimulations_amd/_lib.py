@@ -118,7 +118,7 @@ SIGNATURES = {
 }
 
 
-def _preload_torch_runtime():
+def _preload_torch_runtime(names=("libamdhip64.so",)):
     """One process can hold only ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
     libamdhip64 / librccl (torch/lib); if liblbm_hip.so pulled in /opt/rocm's copies first, a
     later `import torch` would find no GPU (measured on the MI355X box).  So when torch is
@@ -135,7 +135,7 @@ def _preload_torch_runtime():
     if spec is None or not spec.submodule_search_locations:
         return
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-    for name in ("libamdhip64.so",):
+    for name in names:
         path = os.path.join(libdir, name)
         if os.path.exists(path):
             ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)

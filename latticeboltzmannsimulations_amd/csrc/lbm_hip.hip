@@ -113,10 +113,16 @@ rccl_api& rccl() {
     static rccl_api a;
     if (a.ok || !a.err.empty()) return a;
     void* h = nullptr;
+    // a copy that is already mapped first, under either name (PyTorch bundles "librccl.so", ROCm installs "librccl.so.1"): two RCCLs
+    // in one process abort in their exit handlers
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    for (const char* n : {"librccl.so", "librccl.so.1"}) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
         if (h) break;
+    }
+    for (const char* n : names) {
+        if (h) break;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!h) { a.err = std::string("dlopen(librccl): ") + dlerror(); return a; }
 #define RCCL_SYM(field, sym)                                                        \

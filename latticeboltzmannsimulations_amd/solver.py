@@ -341,10 +341,12 @@ def _npz(path):
 
 
 def _one_rccl():
-    """One RCCL per process.  The library binds RCCL with dlopen on the first lbm_comm_* call and takes the copy that is already
-    mapped; PyTorch ships its own librccl.so and maps it when torch is imported.  If torch came AFTER the library had mapped
-    /opt/rocm's, the process would hold two RCCLs and abort in their exit handlers ("double free or corruption", measured:
-    tools/probes/order_test.py) -- so where torch is installed it is imported before the first RCCL call."""
+    """PyTorch before RCCL.  The library binds RCCL with dlopen on the first lbm_comm_* call (the copy already mapped, else torch's
+    bundled one, else /opt/rocm's).  A process that created a communicator through the library and imported torch only AFTERWARDS
+    aborted in the exit handlers ("double free or corruption") -- also with torch's own librccl.so mapped by path beforehand, so it
+    is the order of initialisation of torch's bundled ROCm libraries that matters, not a second RCCL (measured:
+    tools/probes/order_test.py, profiles/r02_logs/rccl_order.log).  Where torch is installed it is therefore imported before the
+    first RCCL call; processes that use this path exchange the communicator id through torch.distributed anyway."""
     import importlib.util
     import sys
     if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
