@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -441,9 +442,23 @@ int ensure_stage(lbm_ctx* c, size_t bytes) {
     return LBM_OK;
 }
 
+// Waiting for the device: poll for a short while, then block.  A blocking hipStreamSynchronize / hipEventSynchronize wakes the host
+// tens of microseconds after the work is done -- 5 % of the driver's 20-step window of 1.1 ms (profiles/r02_logs/unit_times.log);
+// a run that is still busy after SPIN_US hands the core back.
+constexpr long long SPIN_US = 3000;
+template <typename Q>
+bool spin_until_ready(Q&& query) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = query();
+        if (e == hipSuccess) return true;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > SPIN_US) return false;
+    }
+}
 int sync_all(lbm_ctx* c) {
-    HIP_TRY(c, hipStreamSynchronize(c->s_compute));
-    HIP_TRY(c, hipStreamSynchronize(c->s_comm));
+    if (!spin_until_ready([&] { return hipStreamQuery(c->s_compute); })) HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    if (!spin_until_ready([&] { return hipStreamQuery(c->s_comm); })) HIP_TRY(c, hipStreamSynchronize(c->s_comm));
     return LBM_OK;
 }
 
@@ -1261,7 +1276,7 @@ int lbm_time_steps(lbm_ctx* c, int nsteps, double* ms) {
     int rc = step_many(c, nsteps);   // (joins the communication stream into s_compute before returning)
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_t1, c->s_compute));
-    HIP_TRY(c, hipEventSynchronize(c->ev_t1));
+    if (!spin_until_ready([&] { return hipEventQuery(c->ev_t1); })) HIP_TRY(c, hipEventSynchronize(c->ev_t1));
     float f = 0.f;
     HIP_TRY(c, hipEventElapsedTime(&f, c->ev_t0, c->ev_t1));
     *ms = (double)f;
