@@ -379,7 +379,7 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
                 const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
                 hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, VT::SEM, S, WIDE, VT::TURB>), dim3(nframe + ntx * nty, c->batch), dim3(512), 0, s,
                                    (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty,
-                                   fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false) ? 1 : 0);
+                                   fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, TILE_FRAME_LDS_BYTES) ? 1 : 0);
             };
             {   // (fp64: the x rim of S >= 4 is two vectors wide)
                 if (steps == 4) { go(std::integral_constant<int, 4>{}, std::false_type{}); return; }
@@ -1096,6 +1096,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->frame_lds = !(p->flags & LBM_FLAG_NO_FRAME_LDS);
         c->frame_wide = !(p->flags & LBM_FLAG_FRAME_NARROW);
         c->edge_first = !(p->flags & LBM_FLAG_NO_EDGE_FIRST);
+        // a lone lattice under the tile kernel: the longest segment (in steps of 8 cells, not below 16) whose pass windows fit the
+        // launch's LDS -- fp64 windows are twice the size (1024^2 fp64, five passes: 32-cell segments 85 KiB, 24-cell 69 KiB)
+        if (!p->frame_seg && one_launch && c->use_tb && !c->stream && c->tb_steps >= 3 && c->frame_lds)
+            while (c->frame_seg > 16 && !frame_lds_fits(c, c->tb_steps, false, 0, TILE_FRAME_LDS_BYTES)) c->frame_seg -= 8;
         c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_DEEP_HALO);
         c->use_nt = (p->flags & LBM_FLAG_NT_ON) ? true : (p->flags & LBM_FLAG_NT_OFF) ? false : (bytes > ((size_t)192 << 20));
         c->lazy_lag = !(p->flags & LBM_FLAG_EAGER_LAG);

@@ -111,6 +111,10 @@ __device__ __forceinline__ R* pass_ptr(const FramePtrs<R>& fp, int j) {   // (se
 
 // LDS bytes a workgroup of the fused frame passes may use (= the tile kernel's buffer)
 constexpr int FRAME_LDS_BYTES = 48 * 1024;
+// ... and inside the tile launch of a lone lattice: two workgroups of 512 threads fill a CU's wave slots at <= 128 VGPRs, so each
+// may take up to half of the 160 KiB of LDS at no cost in occupancy; the windows of 64-cell segments (fp32, five passes: 73 KiB)
+// then fit and the frame chain -- the critical path of small and medium lattices -- stops going through the scratch lattices
+constexpr int TILE_FRAME_LDS_BYTES = 76 * 1024;
 
 template <typename R, int COLL, int SEM, bool TURB, int NT>
 __device__ __forceinline__ void frame_passes(const FramePtrs<R>& fp, long long boff, const Geo& geo, const Relax<R>& w, int F, int S,
@@ -218,14 +222,15 @@ __global__ __launch_bounds__(512, 4) void k_stepS_deep(const R* __restrict__ src
     constexpr int V = 16 / (int)sizeof(R), PVC = WIDE ? 32 : 16, PH = 512 / PVC;
     constexpr int RV = (S - 1 + V - 1) / V;        // rim vectors per side: 1, or 2 for fp64 beyond three steps
     constexpr int TX = (PVC - 2 * RV) * V, TY = PH - 2 * (S - 1), PW = TX + 2 * RV * V;
-    __shared__ __align__(16) R lds_raw[TB_LDS_PLANES * PH * PW + 2 * V];   // one vector of slack at each end: rim columns
+    constexpr int TILE_ELEMS = TB_LDS_PLANES * PH * PW + 2 * V, FRAME_ELEMS = TILE_FRAME_LDS_BYTES / (int)sizeof(R);
+    __shared__ __align__(16) R lds_raw[TILE_ELEMS > FRAME_ELEMS ? TILE_ELEMS : FRAME_ELEMS];   // one vector of slack at each end: rim columns
     if ((int)blockIdx.x < nframe) {                                         // read one element past their row
         // A lone lattice: the first nframe workgroups of the launch do the S frame passes (frame_passes), the rest the tiles --
         // one launch per S steps and no cross-stream dependency (between slabs the frame stays a launch of its own on the
         // communication stream: nframe = 0).  The frame workgroups run S dependent passes and take the longest: they go first.
         long long boff = 0;
         if (bt.w) { boff = (long long)blockIdx.y * bt.stride; w = bt.w[blockIdx.y]; }
-        static_assert(sizeof(lds_raw) >= FRAME_LDS_BYTES, "frame window buffer");
+        static_assert(sizeof(lds_raw) >= TILE_FRAME_LDS_BYTES, "frame window buffer");
         frame_passes<R, COLL, SEM, TURB, 512>(fp, boff, geo, w, F, S, nsegx, nsegy, 0, 0, (int)blockIdx.x, seg, use_lds ? lds_raw : nullptr);
         return;
     }
