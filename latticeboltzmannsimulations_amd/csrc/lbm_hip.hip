@@ -78,6 +78,7 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
     bool use_tb = false;        // several steps per launch (temporal blocking)
+    bool edge_reserve = true;   // streaming kernel between slabs: a one-round bulk launch leaves CUs to the edge workgroups (A/B: LBM_FLAG_NO_EDGE_RESERVE)
     bool edge_first = true;     // streaming kernel between slabs: release the bulk launch behind the edge launch (A/B: LBM_FLAG_NO_EDGE_FIRST)
     bool frame_wide = true;     // frame passes through the scratch lattices: workgroups of 1024 threads (A/B: LBM_FLAG_FRAME_NARROW)
     bool frame_beside = false;  // streaming kernel of a lone lattice: the frame passes as a kernel of their own on the second stream, BESIDE the
@@ -297,18 +298,47 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
 // Segments of the streaming kernel: strips of 64 V - 2 R useful columns, each cut into nsegy segments of H rows; one
 // workgroup per segment and ONE workgroup per CU, so the plan minimises rounds x iterations per segment (a segment of H rows
 // takes H + 2 (S - 1) rows through the pipeline plus its fill).
+bool has_neighbour(const lbm_ctx* c, int side);
+bool is_slab(const lbm_ctx* c);
 struct StreamPlan { int nstrips, nsegy, H; };
-StreamPlan plan_stream(const lbm_ctx* c, int S) {
+StreamPlan plan_stream_on(const lbm_ctx* c, int S, int ncu, long long* cost_out) {
     const int V = 16 / c->es, Rr = stream_rim(S, V), TXu = 64 * V - 2 * Rr, F = c->tb_f;
     const int cols = c->geo.nx - 2 * F, rows = c->geo.ny - 2 * F;
     StreamPlan best{(cols + TXu - 1) / TXu, 1, rows};
     long long best_cost = -1;
     for (int n = 1; n <= 256 && n * 8 <= std::max(rows, 8); ++n) {
         const int H = (rows + n - 1) / n, nseg = (rows + H - 1) / H;
-        const long long segs = (long long)best.nstrips * nseg, rounds = (segs + c->ncu - 1) / c->ncu;
+        const long long segs = (long long)best.nstrips * nseg, rounds = (segs + ncu - 1) / ncu;
         const long long iters = (H + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
         const long long cost = rounds * iters;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best.nsegy = nseg; best.H = H; }
+    }
+    if (cost_out) *cost_out = best_cost;
+    return best;
+}
+// Between slabs the unit has an edge launch beside the bulk launch (multi_step).  A bulk launch of ONE round takes every CU for its
+// whole run, the edge workgroups (a CU each, ~48 pipeline iterations) then run after it and the next exchange after them: the
+// unit costs bulk + edges.  For a short slab it is cheaper to plan the bulk launch on fewer CUs and leave the others to the edge
+// workgroups (4096 x 512 fp32 slab in loopback: 145 -> 176 GLUPS; taller slabs lose a few per cent -- 4096 x 1024 247 -> 240, 4096 x
+// 2048 282 -> 270 -- hence the limit below; profiles/r02_logs/slab_loopback9.log).  Costs in pipeline iterations.
+StreamPlan plan_stream(const lbm_ctx* c, int S) {
+    long long cost0 = 0;
+    const StreamPlan p0 = plan_stream_on(c, S, c->ncu, &cost0);
+    if (!(is_slab(c) && c->deep_halo && c->frame_fused && c->edge_reserve) || S < 3) return p0;
+    if ((long long)p0.nstrips * p0.nsegy > c->ncu) return p0;     // several rounds: the bulk launch is released behind the edge launch instead
+    const int nb = (has_neighbour(c, LBM_SIDE_LOW) ? 1 : 0) + (has_neighbour(c, LBM_SIDE_HIGH) ? 1 : 0), L = c->frame_seg;
+    const long long n_edge = (long long)nb * p0.nstrips + 2LL * ((c->geo.ny + L - 1) / L) + (2LL - nb) * ((c->geo.nx + L - 1) / L);
+    const long long edge_it = (c->tb_f + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
+    if (2 * cost0 > 3 * edge_it) return p0;   // (measured: a bulk launch longer than ~1.5 edge workgroups overlaps them well enough as it is)
+    StreamPlan best = p0;
+    long long best_cost = cost0 + edge_it * ((n_edge + c->ncu - 1) / c->ncu);
+    for (int div = 1; div <= 3; ++div) {
+        const long long r = (n_edge + div - 1) / div;
+        if (r < 1 || r > c->ncu / 2) continue;
+        long long cb = 0;
+        const StreamPlan p = plan_stream_on(c, S, c->ncu - (int)r, &cb);
+        const long long cost = std::max(cb, edge_it * ((n_edge + r - 1) / r));
+        if (cost < best_cost) { best_cost = cost; best = p; }
     }
     return best;
 }
@@ -1039,11 +1069,12 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
             return (delete c, bail("kernel = STREAM takes one lattice (no batch) with nx % (16 / sizeof(real)) == 0, nx >= 64, ny_local >= 64 (on every rank)"));
         // AUTO (profiles/r02_logs/stream_ab3.log, slab_loopback5.log; fast MRT, GLUPS stream / tile): lone 2048^2 219 / 238, 4096 x 1024 229 /
         // 240, 4096 x 2048 296 / 268, 3072^2 306 / 274, fp64 8192 x 1024 157 / 129 -> from 8 Mi cells.  A slab (its tile-kernel
-        // unit is bound by the chain exchange -> frame passes -> exchange, the streaming unit is not): 4096 x 512 143 / 139,
-        // 2048^2 200 / 185, 4096 x 1024 247 / 181, 4096 x 2048 280 / 233, fp64 8192 x 1024 133 / 117 -> from 4 Mi cells.  Lattices
+        // unit is bound by the chain exchange -> frame passes -> exchange, the streaming unit is not): 4096 x 512 176 / 151,
+        // 2048^2 200 / 185, 4096 x 1024 247 / 181, 4096 x 2048 280 / 233, fp64 8192 x 1024 133 / 117 -> from 2 Mi cells and 512 rows.  Lattices
         // narrower than 2048 (few strips, not measured) keep the earlier 3072^2 rule.
         const long long cells_plan = (long long)p->nx * ny_plan;
-        const bool stream_pays = p->nx >= 2048 ? cells_plan >= ((slab ? 4LL : 8LL) << 20) : cells_plan >= 3072LL * 3072;
+        const bool stream_pays = p->nx >= 2048 ? (slab ? cells_plan >= (2LL << 20) && ny_plan >= 512 : cells_plan >= (8LL << 20))
+                                               : cells_plan >= 3072LL * 3072;
         c->stream = can_stream && (p->kernel == LBM_KERNEL_STREAM || (p->kernel == LBM_KERNEL_AUTO && stream_pays));
         if (c->stream) {
             c->use_tb = true;
@@ -1096,6 +1127,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->frame_lds = !(p->flags & LBM_FLAG_NO_FRAME_LDS);
         c->frame_wide = !(p->flags & LBM_FLAG_FRAME_NARROW);
         c->edge_first = !(p->flags & LBM_FLAG_NO_EDGE_FIRST);
+        c->edge_reserve = !(p->flags & LBM_FLAG_NO_EDGE_RESERVE);
         // a lone lattice under the tile kernel: the longest segment (in steps of 8 cells, not below 16) whose pass windows fit the
         // launch's LDS -- fp64 windows are twice the size (1024^2 fp64, five passes: 32-cell segments 85 KiB, 24-cell 69 KiB)
         if (!p->frame_seg && one_launch && c->use_tb && !c->stream && c->tb_steps >= 3 && c->frame_lds)
