@@ -904,6 +904,32 @@ def test_rccl_exchange_path_in_loopback(dtype, coll, turb, arith, kernel, layout
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("kernel", ["tb", "stream"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rccl_loopback_with_mrt_py_windows(kernel, dtype):
+    """MRT.py's truncated streaming windows between slabs: no deep halo (the left wall reads values parked in ghost columns), so a
+    multi-step unit exchanges one row after every frame pass -- with the tile kernel and with the streaming kernel as the bulk
+    launch (frame width S + 1).  Expected: the same slab stepped one step at a time with the caller moving the rows."""
+    from latticeboltzmannsimulations_amd.slab import LOW, HIGH
+    nx, NY, rows = 512, 300, (100, 96)
+    a = CavitySolver(nx, NY, 1000.0, RT="SRT", semantics="mrt_py", dtype=dtype, rows=rows, kernel=kernel)
+    b = CavitySolver(nx, NY, 1000.0, RT="SRT", semantics="mrt_py", dtype=dtype, rows=rows, kernel="generic")
+    a.comm_loopback()
+    up = np.empty(b.halo_elems(), dtype=dtype); down = np.empty(b.halo_elems(), dtype=dtype)
+    units = set()
+    for steps in (19, 8, 1, 10):
+        units.add(a.next_unit(steps))
+        a.step(steps)
+        for _ in range(steps):
+            b.step_edges(); b.step_interior(); b.step_finish()
+            b.halo_export(LOW, up.ctypes.data); b.halo_export(HIGH, down.ctypes.data)
+            b.halo_import(HIGH, up.ctypes.data); b.halo_import(LOW, down.ctypes.data)
+        fa, fb = a.get_fields(want_fin=True), b.get_fields(want_fin=True)
+        assert all(np.array_equal(x, y) for x, y in zip(fa, fb)), steps
+    assert max(units) >= 3, units
+    a.close(); b.close()
+
+
 def test_slab_without_a_communicator_is_refused():
     """lbm_step / lbm_time_steps on a slab with no transport attached would read ghost rows nobody fills: LBM_ERR_STATE."""
     with CavitySolver(256, 128, 100.0, rows=(0, 64)) as s:
