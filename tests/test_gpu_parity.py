@@ -930,6 +930,27 @@ def test_rccl_loopback_with_mrt_py_windows(kernel, dtype):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("nx,rows,dtype", [(4096, 512, np.float32), (4096, 1024, np.float32), (16384, 2048, np.float32), (8192, 1024, np.float64)])
+def test_streaming_slab_units_at_benchmark_sizes_in_loopback(nx, rows, dtype):
+    """The two-stream schedule of a slab's unit under the streaming kernel at the sizes the scaling runs use, where launches really
+    overlap: edge launch + bulk launch + exchange under the bulk launch, with the bulk launch planned on fewer CUs (4096 x 512), in
+    one round (4096 x 1024) or released behind the edge launch (16384 x 2048, 8192 x 1024 fp64).  A middle slab in RCCL loopback,
+    several calls, 173 steps; expected: the same slab advanced one step per launch with one exchange per step (kernel = vec, same
+    loopback), bit for bit -- same arithmetic (fast) in both."""
+    a = CavitySolver(nx, 3 * rows, 3200.0, RT="MRT", dtype=dtype, rows=(rows, rows), arith="fast")
+    b = CavitySolver(nx, 3 * rows, 3200.0, RT="MRT", dtype=dtype, rows=(rows, rows), arith="fast", kernel="vec")
+    a.comm_loopback(); b.comm_loopback()
+    assert a.describe()["kernel"] == "k_stream" and a.describe()["slab"] == 1
+    for steps in (1, 64, 27, 81):
+        a.step(steps); b.step(steps)
+    assert a.next_unit(100) == 8 and b.next_unit(100) == 1
+    fa, fb = a.get_fields(want_fin=True), b.get_fields(want_fin=True)
+    own = slice(rows, 2 * rows)
+    assert np.array_equal(fa[2][:, :, own], fb[2][:, :, own]) and np.array_equal(fa[0][:, :, own], fb[0][:, :, own])
+    assert np.array_equal(fa[1][:, own], fb[1][:, own]) and np.isfinite(fa[2][:, :, own]).all()
+    a.close(); b.close()
+
+
 def test_slab_without_a_communicator_is_refused():
     """lbm_step / lbm_time_steps on a slab with no transport attached would read ghost rows nobody fills: LBM_ERR_STATE."""
     with CavitySolver(256, 128, 100.0, rows=(0, 64)) as s:
