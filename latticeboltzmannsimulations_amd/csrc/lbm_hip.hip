@@ -1096,7 +1096,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
             // operators without the Smagorinsky closure -- and only in fp64, where it pays: 4096 x 4096 fast MRT 153 -> 169 GLUPS;
             // in fp32 the frame waves slow the streaming waves by more than the 43 us they save, 367 -> 338
             // (profiles/r02_logs/stream_ab18.log)
-            if (p->flags & LBM_FLAG_FRAME_BESIDE_ON) c->frame_beside = true;
+            if (slab) c->frame_beside = false;   // (a slab's frame is its edge launch, multi_step)
+            else if (p->flags & LBM_FLAG_FRAME_BESIDE_ON) c->frame_beside = true;
             else if (!(p->flags & LBM_FLAG_FRAME_BESIDE_OFF) && c->batch == 1 && c->es == 8) {
                 int rs = 1 << 20, rf = 1 << 20;
                 dispatch(c->p, [&](auto v) {
@@ -1132,6 +1133,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // launch's LDS -- fp64 windows are twice the size (1024^2 fp64, five passes: 32-cell segments 85 KiB, 24-cell 69 KiB)
         if (!p->frame_seg && one_launch && c->use_tb && !c->stream && c->tb_steps >= 3 && c->frame_lds)
             while (c->frame_seg > 16 && !frame_lds_fits(c, c->tb_steps, false, 0, TILE_FRAME_LDS_BYTES)) c->frame_seg -= 8;
+        // the same for the frame workgroups inside a launch of the streaming kernel (144 KiB; fp64, eight passes: 40-cell segments):
+        // 4096^2 fp64 strict 113 -> 117 GLUPS, fast with the frame inside 162 -> 171, slab 8192 x 1024 in loopback 142 -> 158
+        if (!p->frame_seg && c->stream && c->frame_lds)
+            while (c->frame_seg > 16 && !frame_lds_fits(c, c->tb_steps, false, 1, ST_LDS_BYTES)) c->frame_seg -= 8;
         c->deep_halo = p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_DEEP_HALO);
         c->use_nt = (p->flags & LBM_FLAG_NT_ON) ? true : (p->flags & LBM_FLAG_NT_OFF) ? false : (bytes > ((size_t)192 << 20));
         c->lazy_lag = !(p->flags & LBM_FLAG_EAGER_LAG);
@@ -1292,10 +1297,10 @@ int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
         wave_updates = wgs * per;
     }
     const int n = std::snprintf(buf, len, "kernel=%s steps_per_launch=%d frame=%d stream=%d vec=%d nt=%d deep_halo=%d frame_fused=%d lazy_lag=%d "
-                                "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d frame_beside=%d",
+                                "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d frame_beside=%d frame_seg=%d",
                                 kern, S, c->use_tb ? c->tb_f : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
                                 c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->geo.row != c->geo.pitch ? "rows" : "planes", wgs, wave_updates, V,
-                                is_slab(c) ? 1 : 0, c->frame_beside ? 1 : 0);
+                                is_slab(c) ? 1 : 0, c->frame_beside ? 1 : 0, c->frame_seg);
     return n < 0 ? LBM_ERR_INVALID : (n >= (int)len ? (int)len - 1 : n);
 }
 
