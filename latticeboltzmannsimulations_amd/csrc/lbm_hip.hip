@@ -78,6 +78,8 @@ struct lbm_ctx {
     bool use_nt = false;        // non-temporal loads/stores: lattice far larger than the 256 MiB Infinity Cache
     bool push = false;          // LBM_KERNEL_PUSH: the reference's two-launch push scheme (lat[0], lat[1]: fin ping-pong; lat[2]: ftemp)
     bool use_tb = false;        // several steps per launch (temporal blocking)
+    int edge_rows = 0;          // rows next to each interface of lat[cur] that work on s_comm wrote (and s_comm's stream order therefore covers):
+                                // the frame width after a multi-step unit, 1 after a single step, 0 at the start of a call (see exchange_ready)
     bool edge_reserve = true;   // streaming kernel between slabs: a one-round bulk launch leaves CUs to the edge workgroups (A/B: LBM_FLAG_NO_EDGE_RESERVE)
     bool edge_first = true;     // streaming kernel between slabs: release the bulk launch behind the edge launch (A/B: LBM_FLAG_NO_EDGE_FIRST)
     bool frame_wide = true;     // frame passes through the scratch lattices: workgroups of 1024 threads (A/B: LBM_FLAG_FRAME_NARROW)
@@ -593,6 +595,16 @@ int enqueue_deep_exchange(lbm_ctx* c, int which, int S) {
     return LBM_OK;
 }
 
+// An exchange is enqueued on s_comm AHEAD of the wait for the previous bulk kernel, so that it runs beside it.  That is only right if
+// the rows it sends were written by work on s_comm itself: the previous unit's frame passes / edge launch (F rows) or edge kernel
+// (one row).  The S rows of a deep exchange after a SINGLE step, and any exchange at the start of a call (the lattice may come from
+// an upload, an import or a recomputation on s_compute), must wait for s_compute first -- found by a soak of several solvers in
+// one process (tools/soak.py seq: the first solver of a process was slow enough to hide it; profiles/r02_logs/soak_bisect2.log).
+int exchange_ready(lbm_ctx* c, int rows) {
+    if (c->edge_rows < rows) HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+    return LBM_OK;
+}
+
 // Every launch unit (one single step or one multi-step) of a slab follows one protocol on the two streams:
 //   s_comm    (highest priority): [the unit's halo exchange -- RCCL, or nothing when the caller has moved the rows] ->
 //                                 waits ev_int (bulk kernel of the previous unit) -> wall / slab-edge work of this unit ->
@@ -607,7 +619,8 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
     if (is_slab(c)) {
         // edge rows 0 and ny-1 (they read the ghost rows) | interior rows
         if (rccl_x && !c->raw[a] && !c->thin_valid) {   // (a raw lattice is not streamed: no halo needed)
-            int rc = enqueue_exchange(c, a);
+            int rc = exchange_ready(c, 1);
+            if (rc == LBM_OK) rc = enqueue_exchange(c, a);
             if (rc) return rc;
         }
         HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
@@ -619,6 +632,7 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
         finish_unit(c, 1);
+        c->edge_rows = 1;
         *comm_used = true;
         return LBM_OK;
     }
@@ -652,7 +666,8 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     const int a = c->cur, b = c->cur ^ 1;
     int rc;
     if (slab && rccl_x && (deep || !c->thin_valid)) {
-        rc = deep ? enqueue_deep_exchange(c, a, S) : enqueue_exchange(c, a);
+        rc = exchange_ready(c, deep ? S : 1);
+        if (rc == LBM_OK) rc = deep ? enqueue_deep_exchange(c, a, S) : enqueue_exchange(c, a);
         if (rc) return rc;
     }
     HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
@@ -694,6 +709,7 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
     finish_unit(c, S);
+    c->edge_rows = c->tb_f;
     *comm_used = true;
     return LBM_OK;
 }
@@ -829,6 +845,7 @@ int step_many(lbm_ctx* c, int nsteps) {
     bool comm_used = false;
     if (c->use_tb || slab)   // (a lone lattice stepping one step per launch uses one stream, no events)
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far (init, upload, earlier calls)
+    c->edge_rows = 0;        // the first exchange of the call waits for it
     int left = nsteps;
     while (left > 0) {
         const int S = unit_steps(c, left, c->raw[c->cur] != 0);
@@ -837,7 +854,8 @@ int step_many(lbm_ctx* c, int nsteps) {
         left -= S;
     }
     if (slab && nsteps > 0 && !c->raw[c->cur]) {   // the populations lbm_get_fields returns for the slab's first / last row need the one-row halo
-        const int rc = enqueue_exchange(c, c->cur);
+        int rc = exchange_ready(c, 1);
+        if (rc == LBM_OK) rc = enqueue_exchange(c, c->cur);
         if (rc) return rc;
         c->thin_valid = true;
         comm_used = true;
@@ -1479,6 +1497,7 @@ int lbm_step_unit(lbm_ctx* c, int S) {
     if (is_slab(c) && !c->deep_halo) return fail(c, LBM_ERR_STATE, "lbm_step_unit on a slab needs the deep halo (MRT_GPU semantics)");
     bool comm_used = false;
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far, the imported rows included
+    c->edge_rows = 0;
     int rc = multi_step(c, &comm_used, S, false);
     if (rc) return rc;
     if (comm_used) return join_comm(c);

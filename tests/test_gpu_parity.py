@@ -951,6 +951,25 @@ def test_streaming_slab_units_at_benchmark_sizes_in_loopback(nx, rows, dtype):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("kernel", ["auto", "tb"])
+def test_deep_exchange_after_a_single_step_waits_for_the_interior_kernel(kernel):
+    """The exchange of a unit is enqueued on the communication stream ahead of the wait for the previous bulk kernel.  After a
+    SINGLE step (the raw first step of a run, a tail) only the slab's first / last row was written on that stream: the S rows of a
+    deep exchange must wait for the interior kernel.  The race only showed on the second and later solvers of a process (the
+    first is slowed by code loading): same slab four times in one process, short calls that start with single steps; expected:
+    every run equals one step and one exchange per launch (kernel = vec)."""
+    nx, rows = 4096, 1024
+    def run(k):
+        with CavitySolver(nx, 3 * rows, 1000.0, RT="MRT", dtype=np.float32, rows=(rows, rows), arith="fast", kernel=k) as s:
+            s.comm_loopback()
+            for n in (9, 1, 17, 2, 10):
+                s.step(n)
+            return s.get_fields(want_fin=True)[2][:, :, rows:2 * rows].copy()
+    ref = run("vec")
+    for _ in range(4):
+        assert np.array_equal(run(kernel), ref)
+
+
 def test_slab_without_a_communicator_is_refused():
     """lbm_step / lbm_time_steps on a slab with no transport attached would read ghost rows nobody fills: LBM_ERR_STATE."""
     with CavitySolver(256, 128, 100.0, rows=(0, 64)) as s:
