@@ -27,8 +27,9 @@ def _worker(rank, world, port, nx, ny, steps, sem, coll, dtype, q):
     from latticeboltzmannsimulations_amd.slab import HaloDriver, partition_rows
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        rows = partition_rows(ny, world)[rank]
-        with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=np.dtype(dtype), rows=rows) as s:
+        parts = partition_rows(ny, world)
+        rows = parts[rank]
+        with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=np.dtype(dtype), rows=rows, min_rows=min(n for _, n in parts)) as s:
             HaloDriver(s, rank, world, device="cpu").step(steps)
             u = np.zeros((2, nx, ny), dtype=dtype); rho = np.zeros((nx, ny), dtype=dtype); fin = np.zeros((9, nx, ny), dtype=dtype)
             s.get_fields(u=u, rho=rho, fin=fin)
@@ -39,11 +40,13 @@ def _worker(rank, world, port, nx, ny, steps, sem, coll, dtype, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,sem,coll,dtype", [(2, "mrt_gpu", "MRT", "float32"), (3, "mrt_py", "SRT", "float64")])
-def test_slab_per_process_over_gloo_equals_single_lattice(world, sem, coll, dtype):
+@pytest.mark.parametrize("world,sem,coll,dtype,nx,ny,steps", [(2, "mrt_gpu", "MRT", "float32", 256, 90, 30), (3, "mrt_py", "SRT", "float64", 256, 90, 30),
+                                                              (2, "mrt_gpu", "MRT", "float32", 4096, 2048, 30)])
+def test_slab_per_process_over_gloo_equals_single_lattice(world, sem, coll, dtype, nx, ny, steps):
     import torch.multiprocessing as mp
     from latticeboltzmannsimulations_amd import CavitySolver
-    nx, ny, steps = 256, 90, 30
+    # (the last case: slabs of 4096 x 1024, which take the streaming kernel -- launch units of 8 steps, edge + bulk launch, with the S rows
+    # per side moved by the HaloDriver between the processes)
     with CavitySolver(nx, ny, 400.0, RT=coll, semantics=sem, dtype=np.dtype(dtype)) as one:
         one.step(steps)
         u1, r1, f1 = one.get_fields(want_fin=True)
