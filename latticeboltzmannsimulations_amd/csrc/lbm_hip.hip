@@ -611,8 +611,8 @@ int exchange_ready(lbm_ctx* c, int rows) {
 //                                 records ev_edges;
 //   s_compute                   : waits ev_edges of the PREVIOUS unit, runs the bulk kernel, records ev_int.
 // The exchange of a unit is enqueued first: it only touches rows that the edge / frame kernels of the previous unit wrote
-// (same stream, in order) and ghost rows, so it runs beside the previous unit's bulk kernel; the small kernels run beside the
-// bulk kernel of the same unit.  Nothing is carried from one unit to the next except thin_valid (a one-row halo that is
+// (same stream, in order) and ghost rows, so it runs beside the previous unit's bulk kernel (exchange_ready() adds the wait for
+// s_compute where that premise does not hold); the small kernels run beside the bulk kernel of the same unit.  Nothing is carried from one unit to the next except thin_valid (a one-row halo that is
 // already in place, e.g. the one lbm_step leaves for lbm_get_fields).
 int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
     const int ny = c->geo.ny, a = c->cur, b = c->cur ^ 1;
@@ -647,7 +647,8 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
 // S steps: lat[a] (state n) -> lat[b] (state n+S).  Bulk: the deep-interior kernel on cells >= tb_f away
 // from walls and slab edges.  Frame: S ordinary single steps on strips of decreasing width (tb_f + S - i for pass i; pass i+1
 // pulls from one cell further out than it writes), through the scratch lattices, the last one into lat[b].
-// Between slabs the frame passes and the exchanges share the second stream, beside the tile kernel.  With the deep halo
+// Between slabs the frame passes and the exchanges share the second stream, beside the tile kernel; under the streaming kernel the
+// frame work of a slab is its edge launch (launch_stream_edges: column strips + the interface rows as short streaming segments).  With the deep halo
 // (MRT_GPU semantics) the row strips of pass i start S - i rows inside the neighbour's rows received before the unit, and that
 // is the unit's only exchange; otherwise every pass but the last is followed by a one-row exchange.  (Running row and
 // column strips as separate launches on separate streams was measured and lost 8 %: profiles/r01_logs/perf31.log, perf35.log.)
