@@ -1535,7 +1535,7 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
         // Neighbours must run the same launch plan (they post matching send / receive sequences): compare it once.
         constexpr int NW = 16;
         const int32_t mine[NW] = {LBM_ABI_VERSION, c->p.nx, c->p.ny, c->p.dtype, c->p.semantics, c->p.turb, c->geo.pitch,
-                                  c->geo.row != c->geo.pitch ? 1 : 0, c->use_tb ? 1 : 0, c->tb_steps, c->tb_f, c->deep_halo ? 1 : 0,
+                                  c->geo.row != c->geo.pitch ? 1 : 0, c->use_tb ? (c->stream ? 2 : 1) : 0, c->tb_steps, c->tb_f, c->deep_halo ? 1 : 0,
                                   c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->p.collision, c->p.arith};
         int32_t* dev = nullptr;
         HIP_TRY(c, hipMalloc((void**)&dev, 3 * NW * sizeof(int32_t)));
@@ -1558,7 +1558,7 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
         (void)hipFree(dev);
         if (r != ncclSuccess) return fail(c, LBM_ERR_COMM, std::string("lbm_comm_init (plan check): ") + rccl().GetErrorString(r));
         if (e != hipSuccess) return fail(c, LBM_ERR_HIP, std::string("lbm_comm_init (plan check): ") + hipGetErrorString(e));
-        static const char* what[NW] = {"ABI version", "nx", "ny", "dtype", "semantics", "turb", "row pitch", "layout", "steps-per-launch path",
+        static const char* what[NW] = {"ABI version", "nx", "ny", "dtype", "semantics", "turb", "row pitch", "layout", "steps-per-launch path (0 none, 1 tile, 2 streaming kernel)",
                                        "steps per launch", "frame width", "deep halo", "fused frame", "lazy lag", "collision", "arith"};
         for (int side = 0; side < 2; ++side) {
             if (!has_neighbour(c, side)) continue;
