@@ -1138,11 +1138,14 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // measured (profiles/r01_logs/perf37.log, perf38.log): one launch per unit instead of S + 1 and no cross-stream dependency:
         // 4096^2 fp32 278 -> 294 GLUPS, 1024^2 fp64 67 -> 91, 1024^2 fp32 96 -> 135; a batch of 64 x 384^2 loses 5 % (its many
         // short frame workgroups do better as separate small launches), so batches keep one launch per pass
-        c->frame_fused = !unfused && (c->batch == 1 || (p->flags & LBM_FLAG_FRAME_FUSED_BATCH));
+        // (r02: with the pass windows of 64-cell segments in the launch's LDS -- 76 KiB, below -- batches gain most from the fused
+        // frame: 64 x 384^2 fp32 fast 132 -> 176 GLUPS aggregate, strict 120 -> 140, fp64 81 -> 86 with 24-cell segments;
+        // profiles/r02_logs/batch_ab.log.  LBM_FLAG_FRAME_FUSED_BATCH is accepted and no longer needed.)
+        c->frame_fused = !unfused;
         // cells of the frame per workgroup (perf43.log): short segments finish a pass in one sweep of the workgroup and suit
         // lattices whose launch is over when the frame chain is (160^2: 4.1 us per step with 16, 6.3 with 64); long ones compute
         // less overlap and suit large lattices (2048^2: 244 GLUPS with 64, 215 with 16)
-        const long long cells1 = (long long)p->nx * ny_plan;
+        const long long cells1 = (long long)p->nx * ny_plan * c->batch;   // (what fills the device: all lattices of a batch)
         c->frame_seg = p->frame_seg ? p->frame_seg : (cells1 <= 512LL * 512 ? 16 : (cells1 <= 1024LL * 1024 ? 32 : 64));
         c->frame_lds = !(p->flags & LBM_FLAG_NO_FRAME_LDS);
         c->frame_wide = !(p->flags & LBM_FLAG_FRAME_NARROW);
@@ -1150,7 +1153,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->edge_reserve = !(p->flags & LBM_FLAG_NO_EDGE_RESERVE);
         // a lone lattice under the tile kernel: the longest segment (in steps of 8 cells, not below 16) whose pass windows fit the
         // launch's LDS -- fp64 windows are twice the size (1024^2 fp64, five passes: 32-cell segments 85 KiB, 24-cell 69 KiB)
-        if (!p->frame_seg && one_launch && c->use_tb && !c->stream && c->tb_steps >= 3 && c->frame_lds)
+        if (!p->frame_seg && (one_launch || (c->batch > 1 && c->frame_fused)) && c->use_tb && !c->stream && c->tb_steps >= 3 && c->frame_lds)
             while (c->frame_seg > 16 && !frame_lds_fits(c, c->tb_steps, false, 0, TILE_FRAME_LDS_BYTES)) c->frame_seg -= 8;
         // the same for the frame workgroups inside a launch of the streaming kernel (144 KiB; fp64, eight passes: 40-cell segments):
         // 4096^2 fp64 strict 113 -> 117 GLUPS, fast with the frame inside 162 -> 171, slab 8192 x 1024 in loopback 142 -> 158
