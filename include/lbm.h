@@ -52,7 +52,7 @@ enum { LBM_SIDE_LOW = 0, LBM_SIDE_HIGH = 1 };           /* slab neighbour toward
 enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange after every frame pass of a multi-step launch instead
                                             of ONE exchange of S complete rows per launch */
        LBM_FLAG_FRAME_UNFUSED = 2,       /* one launch per frame pass instead of all passes inside the tile launch */
-       LBM_FLAG_FRAME_FUSED_BATCH = 4,   /* batches too run the frame passes inside the tile launch */
+       LBM_FLAG_FRAME_FUSED_BATCH = 4,   /* (r01: batches too run the frame passes inside the tile launch; the default since r02, accepted) */
        LBM_FLAG_NO_FRAME_LDS = 8,        /* intermediate frame passes through scratch lattices instead of LDS windows */
        LBM_FLAG_NT_ON = 16,              /* non-temporal loads / stores on (default: lattices above 192 MiB) ... */
        LBM_FLAG_NT_OFF = 32,             /* ... or off */
