@@ -80,6 +80,7 @@ struct lbm_ctx {
     bool use_tb = false;        // several steps per launch (temporal blocking)
     int edge_rows = 0;          // rows next to each interface of lat[cur] that work on s_comm wrote (and s_comm's stream order therefore covers):
                                 // the frame width after a multi-step unit, 1 after a single step, 0 at the start of a call (see exchange_ready)
+    bool xcd_bands = true;      // streaming kernel: contiguous runs of segments per XCD (A/B: LBM_FLAG_NO_XCD_BANDS)
     bool edge_reserve = true;   // streaming kernel between slabs: a one-round bulk launch leaves CUs to the edge workgroups (A/B: LBM_FLAG_NO_EDGE_RESERVE)
     bool edge_first = true;     // streaming kernel between slabs: release the bulk launch behind the edge launch (A/B: LBM_FLAG_NO_EDGE_FIRST)
     bool frame_wide = true;     // frame passes through the scratch lattices: workgroups of 1024 threads (A/B: LBM_FLAG_FRAME_NARROW)
@@ -358,7 +359,7 @@ int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_
         const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
         hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(nframe + pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s,
                            (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, F, xe, ye, pl.nstrips, pl.H,
-                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, ST_LDS_BYTES) ? 1 : 0, 0, 0, 0);
+                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, ST_LDS_BYTES) ? 1 : 0, 0, 0, 0, c->xcd_bands ? 1 : 0);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -385,7 +386,7 @@ int launch_stream_edges(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool
         hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(nframe + pl.nstrips * ((lo ? 1 : 0) + (hi ? 1 : 0))), dim3(ST_NT), 0, s,
                            (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, F, xe, ye, pl.nstrips, pl.H,
                            fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, extra, ST_LDS_BYTES) ? 1 : 0, lo ? 1 + extra : 0,
-                           hi ? 1 + extra : 0, bands);
+                           hi ? 1 + extra : 0, bands, 0);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -1152,6 +1153,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->frame_wide = !(p->flags & LBM_FLAG_FRAME_NARROW);
         c->edge_first = !(p->flags & LBM_FLAG_NO_EDGE_FIRST);
         c->edge_reserve = !(p->flags & LBM_FLAG_NO_EDGE_RESERVE);
+        c->xcd_bands = !(p->flags & LBM_FLAG_NO_XCD_BANDS);
         // a lone lattice under the tile kernel: the longest segment (in steps of 8 cells, not below 16) whose pass windows fit the
         // launch's LDS -- fp64 windows are twice the size (1024^2 fp64, five passes: 32-cell segments 85 KiB, 24-cell 69 KiB)
         if (!p->frame_seg && (one_launch || (c->batch > 1 && c->frame_fused)) && c->use_tb && !c->stream && c->tb_steps >= 3 && c->frame_lds)

@@ -186,14 +186,20 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
 template <typename R, int COLL, int SEM, bool TURB>
 __global__ __launch_bounds__(ST_NT) void k_stream(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int S, int F, int xe, int ye,
                                                   int nstrips, int H, FramePtrs<R> fp, int nframe, int nsegx, int nsegy, int seg, int use_lds,
-                                                  int lo, int hi, int bands) {
+                                                  int lo, int hi, int bands, int xcd_bands) {
     __shared__ __align__(16) R lds[ST_LDS_BYTES / sizeof(R)];
     if ((int)blockIdx.x < nframe) {
         frame_passes<R, COLL, SEM, TURB, ST_NT>(fp, 0, geo, w, F, S, nsegx, nsegy, lo, hi, (int)blockIdx.x, seg, use_lds ? lds : nullptr, bands);
         return;
     }
     constexpr int V = 16 / (int)sizeof(R);
-    const int b = blockIdx.x - nframe;
+    int b = blockIdx.x - nframe;
+    if (xcd_bands) {
+        // consecutive workgroups go to consecutive XCDs (each with its own L2): give every XCD a contiguous run of segments, so
+        // that the strips that share rim columns -- read at the same time, the workgroups march in step -- share an L2
+        const int per = ((int)gridDim.x - nframe) >> 3;
+        if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
+    }
     const int strip = b % nstrips, sy = b / nstrips;
     const int R_ = stream_rim(S, V);
     const int xs = F - R_ + strip * (64 * V - 2 * R_);
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(ST_NT) void k_stream(const R* __restrict__ src, R* 
 #endif
 #define LBM_STREAM_ONE(R, COLL, SEM, TURB)                                                                               \
     LBM_STREAM_EXTERN template __global__ void k_stream<R, COLL, SEM, TURB>(const R* __restrict__, R* __restrict__, Geo, Relax<R>, int, int, int, int, \
-                                                                          int, int, FramePtrs<R>, int, int, int, int, int, int, int, int);
+                                                                          int, int, FramePtrs<R>, int, int, int, int, int, int, int, int, int);
 #define LBM_STREAM_ALL(R)                                                                                                \
     LBM_STREAM_ONE(R, C_SRT, SEM_GPU, false) LBM_STREAM_ONE(R, C_TRT, SEM_GPU, false) LBM_STREAM_ONE(R, C_MRT, SEM_GPU, false)          \
     LBM_STREAM_ONE(R, C_MRT_FAST, SEM_GPU, false) LBM_STREAM_ONE(R, C_SRT_FAST, SEM_GPU, false) LBM_STREAM_ONE(R, C_TRT_FAST, SEM_GPU, false) \
