@@ -217,6 +217,21 @@ class HaloDriver(_UnitDriver):
                    lambda side, ptr: self.st.halo_import_rows(side, nrows, ptr))
 
 
+def global_mean_u(solver, world=1, group=None, device="cpu"):
+    """mean(u) over the WHOLE lattice -- the quantity MRT_GPU.py:883-889 tests for convergence -- from slabs: every rank reduces its
+    own rows on its GPU (lbm_mean_u, 8 bytes leave the device) and ONE all-reduce of a double sums the row-weighted means
+    (the only collective the path may want, once per Pinterval, not per step).  `solver`: a CavitySolver holding a
+    slab (or anything with mean_u(), ny_local and ny)."""
+    part = float(solver.mean_u()) * int(solver.ny_local)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([part], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        part = float(t[0])
+    return part / int(solver.ny)
+
+
 def attach_rccl(solver, rank, world, group=None):
     """Production path: give `solver` (a CavitySolver holding slab `rank`) an RCCL
     communicator so that lbm_step() exchanges halos itself.  torch.distributed (any backend)

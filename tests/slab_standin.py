@@ -63,6 +63,18 @@ class SlabStandIn:
             self.feq = on.equ(rho, ux, uy, o.t)
             self.fpost[:, :, 1:self.n + 1] = o.collide(f, rho, self.feq)
 
+    # what slab.global_mean_u needs of a CavitySolver: the mean of u over the slab's own rows (lbm_mean_u), its rows, the lattice height
+    @property
+    def ny_local(self):
+        return self.n
+
+    @property
+    def ny(self):
+        return self.NY
+
+    def mean_u(self):
+        return float(np.asarray(self.u, dtype=np.float64).mean())
+
     def halo_elems(self):
         return 3 * self.nx
 

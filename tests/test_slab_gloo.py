@@ -77,7 +77,8 @@ def _worker(rank, world, port, nx, ny, steps, sem, coll, q, unit=1):
         drv = HaloDriver(st, rank, world, device="cpu")
         for n in (steps if isinstance(steps, (list, tuple)) else [steps]):
             drv.step(n)
-        q.put((rank, rows, st.fin, st.u, st.rho))
+        from latticeboltzmannsimulations_amd.slab import global_mean_u
+        q.put((rank, rows, st.fin, st.u, st.rho, global_mean_u(st, world)))     # (one all-reduce of a double: SURVEY 8(e))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -106,3 +107,6 @@ def test_gloo_halo_driver_equals_single_domain(world, sem, coll, unit, ny, steps
     u = np.concatenate([g[3] for g in got], axis=2)
     rho = np.concatenate([g[4] for g in got], axis=1)
     assert np.array_equal(fin, ref.fin) and np.array_equal(u, ref.u) and np.array_equal(rho, ref.rho)
+    # the convergence quantity of MRT_GPU.py:883 from the slabs: every rank got the same whole-lattice mean
+    means = [g[5] for g in got]
+    assert max(means) - min(means) < 1e-15 and abs(means[0] - float(ref.u.mean())) < 1e-12
