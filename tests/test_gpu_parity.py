@@ -521,11 +521,14 @@ def test_slab_restart_from_global_state():
 
 @pytest.mark.parametrize("Re,n,RT,dtype,tol,arith", [(100, 128, "MRT", np.float64, 0.03, "strict"), (1000, 256, "MRT", np.float32, 0.05, "strict"),
                                                      (1000, 256, "SRT", np.float64, 0.05, "strict"), (1000, 256, "MRT", np.float32, 0.05, "fast"),
-                                                     (100, 128, "MRT", np.float64, 0.03, "fast")])
+                                                     (100, 128, "MRT", np.float64, 0.03, "fast"),
+                                                     # the streaming kernel (what the benchmark lattices run), eight steps per launch
+                                                     (1000, 256, "MRT", np.float32, 0.05, "fast:stream"), (100, 128, "MRT", np.float64, 0.03, "strict:stream")])
 def test_converged_cavity_matches_ghia(Re, n, RT, dtype, tol, arith):
     """T7 (physics): run to the reference's convergence criterion (MRT_GPU.py:883-889) and compare the centrelines
     with Ghia et al. at the geometrically correct positions; global mass drift stays small."""
-    with CavitySolver(n, n, float(Re), RT=RT, dtype=dtype, arith=arith) as s:
+    arith, _, kernel = arith.partition(":")
+    with CavitySolver(n, n, float(Re), RT=RT, dtype=dtype, arith=arith, kernel=kernel or "auto") as s:
         prev, quiet = None, 0
         for _ in range(400):
             s.step(3000)
