@@ -32,6 +32,19 @@ def same(solver, oracle, what="state"):
     assert np.array_equal(rho, oracle.rho), f"{what}: rho differs"
 
 
+def _smooth_state(nx, ny, dtype):
+    """A smooth non-trivial state for slabs in loopback: such a slab never sees the lid, so from the rest state all its rows stay
+    equal and a kernel that read a stale or not-yet-written row would go unnoticed."""
+    x = np.arange(nx, dtype=np.float64)[:, None]
+    y = np.arange(ny, dtype=np.float64)[None, :]
+    base = 1.0 + 1e-3 * np.sin(0.01 * x) * np.cos(0.013 * y) + 5e-4 * np.cos(0.0037 * (x + 2 * y))
+    t = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
+    fin = np.empty((9, nx, ny), dtype=dtype)
+    for k in range(9):
+        fin[k] = (base * (t[k] * (1.0 + 1e-4 * k))).astype(dtype)
+    return fin
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("sem", ["mrt_py", "mrt_gpu"])
 @pytest.mark.parametrize("coll", ["SRT", "TRT", "MRT"])
@@ -894,6 +907,8 @@ def test_rccl_exchange_path_in_loopback(dtype, coll, turb, arith, kernel, layout
                      tuning=dict(deep_halo=deep))
     b = CavitySolver(nx, NY, 1000.0, RT=coll, dtype=dtype, rows=rows, turb=turb, kernel="generic", layout=layout, arith=arith)
     a.comm_loopback()
+    fin0 = _smooth_state(nx, NY, dtype)     # (from the rest state a slab in loopback would stay uniform: a stale row would not show)
+    a.set_state(fin0); b.set_state(fin0)
     up = np.empty(b.halo_elems(), dtype=dtype); down = np.empty(b.halo_elems(), dtype=dtype)
     for steps in (23, 8, 1, 10):   # several calls: each starts from the one-row halo the previous one left
         a.step(steps)
@@ -918,6 +933,8 @@ def test_rccl_loopback_with_mrt_py_windows(kernel, dtype):
     a = CavitySolver(nx, NY, 1000.0, RT="SRT", semantics="mrt_py", dtype=dtype, rows=rows, kernel=kernel)
     b = CavitySolver(nx, NY, 1000.0, RT="SRT", semantics="mrt_py", dtype=dtype, rows=rows, kernel="generic")
     a.comm_loopback()
+    fin0 = _smooth_state(nx, NY, dtype)
+    a.set_state(fin0); b.set_state(fin0)
     up = np.empty(b.halo_elems(), dtype=dtype); down = np.empty(b.halo_elems(), dtype=dtype)
     units = set()
     for steps in (19, 8, 1, 10):
@@ -943,6 +960,9 @@ def test_streaming_slab_units_at_benchmark_sizes_in_loopback(nx, rows, dtype):
     a = CavitySolver(nx, 3 * rows, 3200.0, RT="MRT", dtype=dtype, rows=(rows, rows), arith="fast")
     b = CavitySolver(nx, 3 * rows, 3200.0, RT="MRT", dtype=dtype, rows=(rows, rows), arith="fast", kernel="vec")
     a.comm_loopback(); b.comm_loopback()
+    fin0 = _smooth_state(nx, 3 * rows, dtype)
+    a.set_state(fin0); b.set_state(fin0)
+    del fin0
     assert a.describe()["kernel"] == "k_stream" and a.describe()["slab"] == 1
     for steps in (1, 64, 27, 81):
         a.step(steps); b.step(steps)
@@ -962,9 +982,11 @@ def test_deep_exchange_after_a_single_step_waits_for_the_interior_kernel(kernel)
     first is slowed by code loading): same slab four times in one process, short calls that start with single steps; expected:
     every run equals one step and one exchange per launch (kernel = vec)."""
     nx, rows = 4096, 1024
+    fin0 = _smooth_state(nx, 3 * rows, np.float32)
     def run(k):
         with CavitySolver(nx, 3 * rows, 1000.0, RT="MRT", dtype=np.float32, rows=(rows, rows), arith="fast", kernel=k) as s:
             s.comm_loopback()
+            s.set_state(fin0)
             for n in (9, 1, 17, 2, 10):
                 s.step(n)
             return s.get_fields(want_fin=True)[2][:, :, rows:2 * rows].copy()

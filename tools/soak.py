@@ -46,6 +46,7 @@ def slab():
         for kernel in ("auto", "auto", "vec"):
             with CavitySolver(nx, 3 * rows, 1000.0, RT="MRT", dtype=dt, rows=(rows, rows), arith=arith, kernel=kernel) as s:
                 s.comm_loopback()
+                s.set_state(smooth_state(nx, 3 * rows, dt))
                 t = time.time()
                 for c in calls:
                     s.step(c)
@@ -61,6 +62,19 @@ def slab():
 
 
 
+def smooth_state(nx, ny, dt):
+    """A smooth non-trivial state (a slab in loopback never sees the lid: from the rest state every row stays equal to every other,
+    and a kernel that read a stale or a not-yet-written row would go unnoticed)."""
+    x = np.arange(nx, dtype=np.float64)[:, None]
+    y = np.arange(ny, dtype=np.float64)[None, :]
+    base = 1.0 + 1e-3 * np.sin(0.01 * x) * np.cos(0.013 * y) + 5e-4 * np.cos(0.0037 * (x + 2 * y))
+    t = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
+    fin = np.empty((9, nx, ny), dtype=dt)
+    for k in range(9):
+        fin[k] = (base * (t[k] * (1.0 + 1e-4 * k))).astype(dt)
+    return fin
+
+
 def one(argv):
     """python3 tools/soak.py one nx rows f32|f64 arith kernel [key=value ...] [calls=a,b,c] -> digest of the slab's populations"""
     nx, rows, dt, arith, kernel = int(argv[0]), int(argv[1]), np.float64 if argv[2] == "f64" else np.float32, argv[3], argv[4]
@@ -73,6 +87,7 @@ def one(argv):
             tune[k] = int(v) if k in ("tb_steps", "frame_seg") else v not in ("0", "false")
     with CavitySolver(nx, 3 * rows, 1000.0, RT="MRT", dtype=dt, rows=(rows, rows), arith=arith, kernel=kernel, tuning=tune) as s:
         s.comm_loopback()
+        s.set_state(smooth_state(nx, 3 * rows, dt))
         for c in calls:
             s.step(c)
         u, rho, fin = s.get_fields(want_fin=True)
