@@ -123,3 +123,36 @@ def test_partition_rows():
     with pytest.raises(ValueError):
         partition_rows(7, 4)
     assert neighbours(0, 4) == (None, 1) and neighbours(3, 4) == (2, None) and neighbours(0, 1) == (None, None)
+
+
+def test_tuning_switches_map_to_lbm_params_flags():
+    """CavitySolver(tuning={...}) -> (tb_steps, frame_seg, flags) of lbm_params: every switch sets exactly its bit, defaults set none,
+    unknown keys are refused (the library reads no environment: this is the only way in)."""
+    from latticeboltzmannsimulations_amd import _lib as L
+    from latticeboltzmannsimulations_amd.solver import _tuning
+    assert _tuning(None) == (0, 0, 0) and _tuning({}) == (0, 0, 0)
+    assert _tuning(dict(tb_steps=4, frame_seg=32)) == (4, 32, 0)
+    off = dict(deep_halo=L.LBM_FLAG_NO_DEEP_HALO, frame_fused=L.LBM_FLAG_FRAME_UNFUSED, frame_lds=L.LBM_FLAG_NO_FRAME_LDS,
+               comm_priority=L.LBM_FLAG_COMM_PRIORITY_OFF, frame_wide=L.LBM_FLAG_FRAME_NARROW, edge_first=L.LBM_FLAG_NO_EDGE_FIRST,
+               edge_reserve=L.LBM_FLAG_NO_EDGE_RESERVE, xcd_bands=L.LBM_FLAG_NO_XCD_BANDS)
+    for key, bit in off.items():
+        assert _tuning({key: False}) == (0, 0, bit) and _tuning({key: True}) == (0, 0, 0), key
+    assert _tuning(dict(eager_lag=True))[2] == L.LBM_FLAG_EAGER_LAG and _tuning(dict(frame_fused_batch=True))[2] == L.LBM_FLAG_FRAME_FUSED_BATCH
+    assert _tuning(dict(nt=True))[2] == L.LBM_FLAG_NT_ON and _tuning(dict(nt=False))[2] == L.LBM_FLAG_NT_OFF
+    assert _tuning(dict(frame_beside=True))[2] == L.LBM_FLAG_FRAME_BESIDE_ON and _tuning(dict(frame_beside=False))[2] == L.LBM_FLAG_FRAME_BESIDE_OFF
+    bits = [getattr(L, n) for n in dir(L) if n.startswith("LBM_FLAG_")]
+    assert len(set(bits)) == len(bits) and all(b & (b - 1) == 0 for b in bits)       # distinct single bits
+    with pytest.raises(ValueError, match="unknown tuning"):
+        _tuning(dict(no_such_switch=True))
+
+
+def test_global_mean_u_of_one_rank_is_the_row_weighted_mean():
+    """slab.global_mean_u without a process group: the slab's mean times its share of the rows (what the all-reduce sums)."""
+    from latticeboltzmannsimulations_amd.slab import global_mean_u
+
+    class Fake:
+        ny_local, ny = 25, 100
+
+        def mean_u(self):
+            return 0.04
+    assert abs(global_mean_u(Fake()) - 0.01) < 1e-15
