@@ -1074,11 +1074,14 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         // S = 4), the factored one is not: S = 3 / 4 / 5 = 184 / 227 / 277 GLUPS; SRT 189 / 237 / 250, with the closure 152 / 188 /
         // 217; MRT + closure 150 / 187 / 202; TRT 185 / 210 / 210, with the closure 152 / 163 / 156
         const bool fast = p->arith == LBM_ARITH_FAST;
-        const int want32 = fast ? (p->collision == LBM_TRT ? 4 : 5) : (trt_turb ? 3 : 4);
+        // r02: with the exact-product multiply-adds of the strict MRT operator (lbm_device.hpp) five steps pay there too
+        // (profiles/r02_logs/strict_steps.log: 4096^2 fp32 226 -> 236 GLUPS, 1024^2 134 -> 145; fp64 2048^2 S = 3 / 4 / 5 = 85 / 97 / 98)
+        const bool mrt_plain = p->collision == LBM_MRT && !p->turb;
+        const int want32 = fast ? (p->collision == LBM_TRT ? 4 : 5) : (trt_turb ? 3 : (mrt_plain ? 5 : 4));
         // fp64 (perf46.log; an x rim of two vectors from four steps on): the factored MRT operator S = 3 / 4 / 5 = 98 / 123 / 142 GLUPS
         // at 4096^2 (8192 x 1024: 91 / 109 / 129); the strict operator is arithmetic-bound (103 / 105 / 103)
         // (SRT + closure fp64: 81 / 88 / 88 GLUPS)
-        const int want64 = p->collision == LBM_MRT ? (fast ? 5 : 3) : 4;
+        const int want64 = p->collision == LBM_MRT ? (fast || mrt_plain ? 5 : 3) : 4;
         // a lone small lattice is bound by the launch, not by arithmetic or bandwidth: more steps per launch whatever the operator
         // (perf52.log, strict: 160^2 fp32 4.33 -> 4.13 us per step with five, fp64 5.02 -> 4.65 with four)
         const bool small_lone = one_launch && (long long)p->nx * ny_plan <= 512LL * 512;
