@@ -64,7 +64,8 @@ enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange af
        LBM_FLAG_FRAME_NARROW = 2048,     /* frame passes that go through the scratch lattices: workgroups of 256 threads instead of 1024 */
        LBM_FLAG_NO_EDGE_FIRST = 4096,    /* streaming kernel between slabs: do not hold the bulk launch back behind the edge launch */
        LBM_FLAG_NO_EDGE_RESERVE = 8192,  /* ... and do not plan a one-round bulk launch on fewer CUs to leave some to the edge workgroups */
-       LBM_FLAG_NO_XCD_BANDS = 16384 };  /* streaming kernel: workgroup i takes segment i (default: every XCD a contiguous run of segments) */
+       LBM_FLAG_NO_XCD_BANDS = 16384,    /* streaming kernel: workgroup i takes segment i (default: every XCD a contiguous run of segments) */
+       LBM_FLAG_NO_TAIL_TILES = 32768 }; /* streaming contexts: units of 3 .. 5 steps through the streaming kernel too (default: the tile kernel) */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
  * reference bakes them into the CUDA source by '%'-formatting (MRT_GPU.py:422,531,662) and

@@ -80,6 +80,7 @@ struct lbm_ctx {
     bool use_tb = false;        // several steps per launch (temporal blocking)
     int edge_rows = 0;          // rows next to each interface of lat[cur] that work on s_comm wrote (and s_comm's stream order therefore covers):
                                 // the frame width after a multi-step unit, 1 after a single step, 0 at the start of a call (see exchange_ready)
+    bool tail_tiles = false;    // streaming contexts (lone, fp32): units of 3 .. 5 steps through the tile kernel (A/B: LBM_FLAG_NO_TAIL_TILES)
     bool xcd_bands = true;      // streaming kernel: contiguous runs of segments per XCD (A/B: LBM_FLAG_NO_XCD_BANDS)
     bool edge_reserve = true;   // streaming kernel between slabs: a one-round bulk launch leaves CUs to the edge workgroups (A/B: LBM_FLAG_NO_EDGE_RESERVE)
     bool edge_first = true;     // streaming kernel between slabs: release the bulk launch behind the edge launch (A/B: LBM_FLAG_NO_EDGE_FIRST)
@@ -392,8 +393,31 @@ int launch_stream_edges(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool
     return LBM_OK;
 }
 
+// The first launch of the streaming kernel in a process costs ~1.4 ms (code upload, 144 KiB of LDS, scratch set-up).  Where the first
+// units of a run may go to the tile kernel (tail_tiles) that cost would land in the middle of a run -- in the driver's 20 timed
+// steps after a 5-step warm-up, for one -- so lbm_create pays it: one workgroup that returns at once (its segment is empty).
+int warm_stream(lbm_ctx* c) {
+    dispatch(c->p, [&](auto v) {
+        using VT = decltype(v);
+        using R = typename VT::R;
+        const int F = c->tb_f;
+        FramePtrs<R> fp;
+        fp.src = (const R*)c->lat[0];
+        for (int i = 0; i < 8; ++i) fp.pass[i] = (R*)c->lat[1];
+        hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
+                           c->geo, relax_of<R>(c->p), c->tb_steps, F, c->geo.nx - F, /*ye=*/F, 1, 1, fp, 0, 1, 1, c->frame_seg, 0, 0, 0, 0, 0);
+    });
+    HIP_TRY(c, hipGetLastError());
+    return LBM_OK;
+}
+
 int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool with_frame = false) {
-    if (c->stream) return launch_stream(c, from, to, s, steps, with_frame);
+    // A short unit of a lone fp32 lattice (the tail of a call: 3 .. 5 steps) goes to the tile kernel: a launch of the streaming
+    // kernel costs nearly the same whatever its length (4096^2 fast: 311 us for four steps, 374 for eight), the tile kernel's four
+    // steps take ~290 (strict ~300 against ~350): the driver's 20 timed steps, fast 1088 -> 1066 us, strict 1466 -> 1412
+    // (profiles/r02_logs/tail_tiles.log)
+    const bool tail = c->stream && c->tail_tiles && with_frame && steps >= 3 && steps <= 5;
+    if (c->stream && !tail) return launch_stream(c, from, to, s, steps, with_frame);
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
@@ -1124,6 +1148,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
             // operators without the Smagorinsky closure -- and only in fp64, where it pays: 4096 x 4096 fast MRT 153 -> 169 GLUPS;
             // in fp32 the frame waves slow the streaming waves by more than the 43 us they save, 367 -> 338
             // (profiles/r02_logs/stream_ab18.log)
+            c->tail_tiles = !slab && c->batch == 1 && c->es == 4 && p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_TAIL_TILES);
             if (slab) c->frame_beside = false;   // (a slab's frame is its edge launch, multi_step)
             else if (p->flags & LBM_FLAG_FRAME_BESIDE_ON) c->frame_beside = true;
             else if (!(p->flags & LBM_FLAG_FRAME_BESIDE_OFF) && c->batch == 1 && c->es == 8) {
@@ -1211,6 +1236,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
             if (lbm_set_relaxation(c, i, p->omega, p->omegam, p->omega_e, p->omega_eps, p->omega_q) != LBM_OK) return cleanup(c->err);
     }
     if (lbm_init_equilibrium(c) != LBM_OK) return cleanup(c->err);
+    if (c->stream && c->tail_tiles && warm_stream(c) != LBM_OK) return cleanup("warm-up launch of the streaming kernel");
     return c;
 }
 

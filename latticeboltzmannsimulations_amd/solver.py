@@ -34,7 +34,8 @@ def _tuning(t):
     tb, seg, flags = int(t.pop("tb_steps", 0) or 0), int(t.pop("frame_seg", 0) or 0), 0
     off = {"deep_halo": L.LBM_FLAG_NO_DEEP_HALO, "frame_fused": L.LBM_FLAG_FRAME_UNFUSED, "frame_lds": L.LBM_FLAG_NO_FRAME_LDS,
            "comm_priority": L.LBM_FLAG_COMM_PRIORITY_OFF, "frame_wide": L.LBM_FLAG_FRAME_NARROW, "edge_first": L.LBM_FLAG_NO_EDGE_FIRST,
-           "edge_reserve": L.LBM_FLAG_NO_EDGE_RESERVE, "xcd_bands": L.LBM_FLAG_NO_XCD_BANDS}
+           "edge_reserve": L.LBM_FLAG_NO_EDGE_RESERVE, "xcd_bands": L.LBM_FLAG_NO_XCD_BANDS,
+           "tail_tiles": L.LBM_FLAG_NO_TAIL_TILES}
     on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG}
     for k, bit in off.items():
         if not t.pop(k, True):
@@ -73,7 +74,7 @@ class CavitySolver:
                    derived from it, so that neighbours run the same exchange protocol
     tuning       : A/B switches of the launch plan, none of which changes a result: tb_steps (2..5 steps per launch),
                    frame_seg, and the boolean flags deep_halo, frame_fused, frame_fused_batch, frame_lds, nt, comm_priority,
-                   eager_lag, frame_beside, frame_wide, edge_first, edge_reserve, xcd_bands (lbm_params.tb_steps / frame_seg / flags)
+                   eager_lag, frame_beside, frame_wide, edge_first, edge_reserve, xcd_bands, tail_tiles (lbm_params.tb_steps / frame_seg / flags)
     """
 
     def __init__(self, xsize, ysize, Re, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0,

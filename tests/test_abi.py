@@ -56,7 +56,7 @@ def test_enums_match_header():
                  "LBM_LAYOUT_AUTO", "LBM_LAYOUT_PLANES", "LBM_LAYOUT_ROWS", "LBM_ARITH_STRICT", "LBM_ARITH_FAST",
                  "LBM_FLAG_NO_DEEP_HALO", "LBM_FLAG_FRAME_UNFUSED", "LBM_FLAG_FRAME_FUSED_BATCH", "LBM_FLAG_NO_FRAME_LDS",
                  "LBM_FLAG_NT_ON", "LBM_FLAG_NT_OFF", "LBM_FLAG_COMM_PRIORITY_OFF", "LBM_FLAG_EAGER_LAG", "LBM_FLAG_FRAME_BESIDE_ON",
-                 "LBM_FLAG_FRAME_BESIDE_OFF", "LBM_FLAG_FRAME_NARROW", "LBM_FLAG_NO_EDGE_FIRST", "LBM_FLAG_NO_EDGE_RESERVE", "LBM_FLAG_NO_XCD_BANDS"):
+                 "LBM_FLAG_FRAME_BESIDE_OFF", "LBM_FLAG_FRAME_NARROW", "LBM_FLAG_NO_EDGE_FIRST", "LBM_FLAG_NO_EDGE_RESERVE", "LBM_FLAG_NO_XCD_BANDS", "LBM_FLAG_NO_TAIL_TILES"):
         m = re.search(name + r"\s*=\s*(-?\d+)", src)
         assert m and int(m.group(1)) == getattr(_lib, name), name
 

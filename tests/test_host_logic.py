@@ -134,7 +134,7 @@ def test_tuning_switches_map_to_lbm_params_flags():
     assert _tuning(dict(tb_steps=4, frame_seg=32)) == (4, 32, 0)
     off = dict(deep_halo=L.LBM_FLAG_NO_DEEP_HALO, frame_fused=L.LBM_FLAG_FRAME_UNFUSED, frame_lds=L.LBM_FLAG_NO_FRAME_LDS,
                comm_priority=L.LBM_FLAG_COMM_PRIORITY_OFF, frame_wide=L.LBM_FLAG_FRAME_NARROW, edge_first=L.LBM_FLAG_NO_EDGE_FIRST,
-               edge_reserve=L.LBM_FLAG_NO_EDGE_RESERVE, xcd_bands=L.LBM_FLAG_NO_XCD_BANDS)
+               edge_reserve=L.LBM_FLAG_NO_EDGE_RESERVE, xcd_bands=L.LBM_FLAG_NO_XCD_BANDS, tail_tiles=L.LBM_FLAG_NO_TAIL_TILES)
     for key, bit in off.items():
         assert _tuning({key: False}) == (0, 0, bit) and _tuning({key: True}) == (0, 0, 0), key
     assert _tuning(dict(eager_lag=True))[2] == L.LBM_FLAG_EAGER_LAG and _tuning(dict(frame_fused_batch=True))[2] == L.LBM_FLAG_FRAME_FUSED_BATCH
