@@ -257,6 +257,13 @@ def main():
         S_dom = max(units) if units else 1
         pure = bool(units) and all(u == S_dom for u in units)
         launch_ms = ev_ms / len(units) if units else float("nan")
+        region_launch_ms = launch_ms
+        if units and not pure and world == 1:
+            # The timed region mixes launch units (e.g. 8 + 8 + 4 steps, the last one on another kernel): its average is not the
+            # duration of the dominant kernel's launch.  Measure that one on its own, right after the timed region: three launches
+            # of S_dom steps, HIP events around them (outside the timed steps, so `value` is untouched).
+            solver.step(2 * S_dom)          # (the device idled while the host got here: two launches bring it back to speed)
+            launch_ms = min(solver.time_steps(3 * S_dom) for _ in range(3)) / 3
         min_bytes_launch = cells_rank * 2 * 9 * es
         hbm_achieved = min_bytes_launch / (launch_ms * 1e-3) / 1e9
         plan = solver.describe()
@@ -280,6 +287,9 @@ def main():
         roof = {"bound": "hbm", "achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(hbm_achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel": kname, "steps_per_launch": S_dom, "launches_timed": len(units), "launch_ms": round(launch_ms, 5),
+                "launch_ms_source": "HIP events over the timed region / its launches" if pure or world > 1 else
+                                    "three launches of the dominant kernel timed right after the timed region (the region mixes unit lengths; "
+                                    f"its own average per launch unit: {region_launch_ms:.5f} ms)",
                 "bytes_per_launch": min_bytes_launch,
                 "traffic_static": True if traffic is not None else None,
                 "traffic_source": tr.get("source") if traffic is not None else None,
