@@ -237,6 +237,47 @@ def test_seeded_random_configurations_against_oracle():
             same(s, o, f"case {case}: {nx}x{ny} {sem} {coll} {np.dtype(dtype).name} turb={turb} {kernel} {layout} {chunks}")
 
 
+def test_seeded_random_configurations_of_the_streaming_kernel():
+    """30 seeded random draws for kernel = stream: ragged widths (last strip partly outside the lattice, one to four strips), heights
+    that no segment count divides, every steps-per-launch 3 .. 8, call lengths that leave every kind of tail (tail units of a lone
+    fp32 lattice go to the tile kernel, the others stay), lone lattices and 2 - 3 slabs driven through the launch-unit API, the
+    closure; strict arithmetic against the oracle, bit for bit, fields (one-step lag) included."""
+    rng = np.random.default_rng(20261005)
+    for case in range(30):
+        dtype = [np.float32, np.float64][rng.integers(2)]
+        V = 4 if dtype == np.float32 else 2
+        coll = ["SRT", "TRT", "MRT"][rng.integers(3)]
+        turb = int(rng.random() < 0.25)
+        sem = "mrt_py" if (not turb and rng.random() < 0.2) else "mrt_gpu"
+        nx = int(rng.integers(64 // V, 900 // V)) * V
+        nslabs = 1 if sem == "mrt_py" else int(rng.integers(1, 4))
+        ny = int(rng.integers(64, 200)) * nslabs + int(rng.integers(0, nslabs))
+        tbs = int(rng.integers(3, 9))
+        Re = [100.0, 1000.0, 5000.0][rng.integers(3)]
+        chunks = [int(v) for v in rng.integers(1, 23, size=3)]
+        tune = dict(tb_steps=tbs, tail_tiles=bool(rng.integers(2)), xcd_bands=bool(rng.integers(2)))
+        what = f"case {case}: {nx}x{ny} {sem} {coll} {np.dtype(dtype).name} turb={turb} S={tbs} slabs={nslabs} {chunks} {tune}"
+        o = CavityOracleC(nx, ny, Re, semantics=sem, collision=coll, dtype=dtype, turb=turb)
+        if nslabs == 1:
+            with CavitySolver(nx, ny, Re, RT=coll, semantics=sem, dtype=dtype, turb=turb, kernel="stream", tuning=tune) as s:
+                for n in chunks:
+                    o.step(n); s.step(n)
+                same(s, o, what)
+            continue
+        parts = partition_rows(ny, nslabs)
+        mr = min(n for _, n in parts)
+        slabs = [CavitySolver(nx, ny, Re, RT=coll, semantics=sem, dtype=dtype, turb=turb, kernel="stream", rows=r, min_rows=mr, tuning=tune)
+                 for r in parts]
+        drv = LocalSlabs(slabs)
+        for n in chunks:
+            o.step(n); drv.step(n)
+        u = np.zeros_like(o.u); rho = np.zeros_like(o.rho); fin = np.zeros_like(o.fin)
+        for sl in slabs:
+            sl.get_fields(u=u, rho=rho, fin=fin)
+            sl.close()
+        assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho), what
+
+
 def test_two_steps_per_launch_needs_its_preconditions():
     with pytest.raises(RuntimeError, match="kernel = TB"):
         CavitySolver(24, 64, 100.0, kernel="tb")
