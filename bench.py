@@ -225,6 +225,10 @@ def main():
     # loaded device before anything is timed (a cold first 200-step window reads ~10 % low: profiles/r01_logs/perf12.log).
     # These are not workload steps; the W warm-up steps of the contract follow.
     wake_gbps = solver.copy_bandwidth(1 << 30, 100)
+    # ... and ~20 ms of packed fp32 FMAs (lbm_fma_rate): the copies leave the core clock where a memory-bound load needs it, the
+    # streaming kernel is as much arithmetic- as memory-bound, and its first launches after copies alone run 6 % slower than in a
+    # long run (tools/probes/wakeup_ab.py, profiles/r02_logs/wakeup_ab.log).  Not workload steps either.
+    wake_tflops = solver.fma_rate(20.0)
     solver.step(a.warmup)
     fence()
     units = unit_plan(solver, a.steps)        # the launches the K timed steps consist of
@@ -309,6 +313,7 @@ def main():
         if not a.no_extra and world == 1:
             try:
                 other["device_copy_GBps"] = round(wake_gbps, 1)
+                other["device_fma_TFLOPs"] = round(wake_tflops, 1)
                 # the same workload advanced ONE step per launch (k_step_vec): the HBM-streaming reference point
                 s1, _, _ = make_solver(a.config, scaling, 1, 0, dev, "vec", "strict")
                 with s1:
@@ -331,6 +336,9 @@ def main():
                         other["strict_arith"] = {"MLUPS": round(cells_total / ms2 / 1e3, 1), "ms_per_step": round(ms2, 5),
                                                  "steps": a.steps, "steps_per_launch": s2.next_unit(1000),
                                                  "note": "reference operation order, bit-identical to the oracle"}
+                if a.steps < 400:   # the same workload over a long window (the driver's K is a 1 ms burst): 800 steps, HIP events
+                    msl = solver.time_steps(800) / 800
+                    other["long_run"] = {"MLUPS": round(cells_total / msl / 1e3, 1), "ms_per_step": round(msl, 5), "steps": 800}
                 # the other BASELINE configurations on this one GPU (whole lattice; c5: the per-GPU slab of the weak series)
                 for cfg, n in (("c2", 200), ("c3f64", 100), ("c4", 50), ("c5", 100)):
                     if cfg == a.config:
@@ -365,7 +373,10 @@ def main():
                                            "to rounding, not bit for bit; the reference-order path is other.strict_arith)" if a.arith == "fast"
                                            else " (reference operation order, bit-identical to the oracle)"),
                        "halo": (f"rccl send/recv inside lbm_step: {S_dom} complete rows per side before each {S_dom}-step launch, overlapped"
-                                if world > 1 else "none")},
+                                if world > 1 else "none"),
+                       "device_wakeup": "before the W warm-up steps, identical for every N, not workload steps: 100 device copies of 1 GiB "
+                                        "(~40 ms) + ~20 ms of packed fp32 FMAs (lbm_fma_rate), so that memory AND core clocks are those of "
+                                        "a loaded device when the warm-up starts"},
             "roofline": roof,
         }
         if other:

@@ -238,6 +238,10 @@ int lbm_comm_loopback(lbm_ctx* c);
 /* Device-to-device streaming copy of `bytes` bytes (read + write), `iters` times; returns
  * achieved (read+write) GB/s: the achievable-bandwidth denominator next to the 8 TB/s peak. */
 int lbm_copy_bandwidth(lbm_ctx* c, size_t bytes, int iters, double* gbps);
+/* About `ms` milliseconds of packed fp32 fused multiply-adds on every CU (nothing else: no memory traffic); returns the achieved
+ * TFLOP/s -- the arithmetic counterpart of lbm_copy_bandwidth, and what bench.py uses, after the copies, to bring the device to the
+ * clocks of an arithmetic-bound load before the warm-up steps. */
+int lbm_fma_rate(lbm_ctx* c, double ms, double* tflops);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,7 @@ SIGNATURES = {
     "lbm_comm_init": (_i, [_vp, _i, _i, _vp]),
     "lbm_comm_loopback": (_i, [_vp]),
     "lbm_copy_bandwidth": (_i, [_vp, ctypes.c_size_t, _i, ctypes.POINTER(_d)]),
+    "lbm_fma_rate": (_i, [_vp, _d, ctypes.POINTER(_d)]),
 }
 
 

@@ -30,6 +30,25 @@ __global__ __launch_bounds__(BLK) void k_copy16(const uint4* __restrict__ a, uin
     for (; i < n; i += stride) b[i] = a[i];
 }
 
+// fp32 fused multiply-add rate probe (lbm_fma_rate): 16 independent packed FMAs per thread and iteration, nothing else
+__global__ __launch_bounds__(BLK) void k_fma_burn(float* __restrict__ sink, int iters, float seed) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = f2{seed + (float)i, seed - (float)threadIdx.x * 1e-6f};
+    const f2 m = f2{0.999f, 1.001f}, b = f2{1e-3f, -1e-3f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(a[i], m, b);
+    }
+    f2 t = a[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += a[i];
+    if (t.x + t.y == 123456.789f) sink[blockIdx.x * BLK + threadIdx.x] = t.x;   // (never true in practice: keeps the loop alive)
+}
+
 // out[z] = scale * (partial[z * nper + 0] + partial[z * nper + 1] + ...), added in index order by one thread per lattice
 __global__ __launch_bounds__(BLK) void k_reduce_final(const double* __restrict__ partial, int nper, int nlat, double scale, double* __restrict__ out) {
     const int z = blockIdx.x * BLK + threadIdx.x;
@@ -1656,6 +1675,31 @@ int lbm_copy_bandwidth(lbm_ctx* c, size_t bytes, int iters, double* gbps) {
     (void)hipFree(b);
     if (e != hipSuccess) return fail(c, LBM_ERR_HIP, std::string("lbm_copy_bandwidth: ") + hipGetErrorString(e));
     *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return LBM_OK;
+}
+
+int lbm_fma_rate(lbm_ctx* c, double ms_total, double* tflops) {
+    if (!c || !tflops || !(ms_total > 0) || ms_total > 2000) return fail(c, LBM_ERR_INVALID, "lbm_fma_rate: bad argument (0 < ms <= 2000)");
+    HIP_TRY(c, hipSetDevice(c->p.device));
+    float* sink = nullptr;
+    const int blocks = c->ncu * 8, iters = 4096;
+    HIP_TRY(c, hipMalloc((void**)&sink, (size_t)blocks * BLK * sizeof(float)));
+    auto run = [&](int n, float* ms) -> hipError_t {
+        (void)hipEventRecord(c->ev_t0, c->s_compute);
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_fma_burn, dim3(blocks), dim3(BLK), 0, c->s_compute, sink, iters, 1.0f + (float)i);
+        (void)hipEventRecord(c->ev_t1, c->s_compute);
+        hipError_t e = hipEventSynchronize(c->ev_t1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, c->ev_t0, c->ev_t1);
+        return e;
+    };
+    float ms1 = 0.f, ms = 0.f;
+    hipError_t e = run(1, &ms1);                                    // calibration (also the first, slower, launch)
+    const int n = e == hipSuccess && ms1 > 0 ? std::max(1, (int)(ms_total / ms1)) : 1;
+    if (e == hipSuccess) e = run(n, &ms);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, std::string("lbm_fma_rate: ") + hipGetErrorString(e));
+    // per thread and iteration: 16 packed FMAs = 32 FMAs = 64 flop
+    *tflops = (double)n * blocks * BLK * (double)iters * 64.0 / (ms * 1e-3) / 1e12;
     return LBM_OK;
 }
 

@@ -308,6 +308,12 @@ class CavitySolver:
         _one_rccl()
         self._check(self.lib.lbm_comm_loopback(self._h), "lbm_comm_loopback")
 
+    def fma_rate(self, ms=20.0):
+        """About `ms` milliseconds of packed fp32 FMAs on every CU; achieved TFLOP/s (lbm_fma_rate)."""
+        g = ctypes.c_double(0.0)
+        self._check(self.lib.lbm_fma_rate(self._h, float(ms), ctypes.byref(g)), "lbm_fma_rate")
+        return g.value
+
     def copy_bandwidth(self, nbytes=1 << 30, iters=10):
         g = ctypes.c_double(0.0)
         self._check(self.lib.lbm_copy_bandwidth(self._h, int(nbytes), int(iters), ctypes.byref(g)), "lbm_copy_bandwidth")

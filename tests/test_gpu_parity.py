@@ -1120,6 +1120,7 @@ def test_timing_and_bandwidth_probes():
         ms = s.time_steps(20)
         assert 0 < ms < 1000
         assert s.copy_bandwidth(1 << 28, 5) > 500.0     # GB/s, any healthy MI355X
+        assert 20.0 < s.fma_rate(5.0) < 200.0           # TFLOP/s of packed fp32 FMAs (vector peak 157)
 
 
 def test_front_end_drop_in(tmp_path, monkeypatch):
