@@ -1138,13 +1138,14 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         if (p->kernel == LBM_KERNEL_STREAM && !can_stream)
             return (delete c, bail("kernel = STREAM takes one lattice (no batch) with nx % (16 / sizeof(real)) == 0, nx >= 64, ny_local >= 64 (on every rank)"));
         // AUTO (profiles/r02_logs/stream_ab3.log, slab_loopback5.log; fast MRT, GLUPS stream / tile): lone 2048^2 219 / 238, 4096 x 1024 229 /
-        // 240, 4096 x 2048 296 / 268, 3072^2 306 / 274, fp64 8192 x 1024 157 / 129 -> from 8 Mi cells.  A slab (its tile-kernel
+        // 240, 4096 x 2048 296 / 268, 3072^2 306 / 274, fp64 8192 x 1024 157 / 129 -> from 8 Mi cells (fp64: 2048^2 134 / 129, 2560^2 150 / 135, 4096 x
+        // 1024 128 / 125 -> from 4 Mi).  A slab (its tile-kernel
         // unit is bound by the chain exchange -> frame passes -> exchange, the streaming unit is not): 4096 x 512 176 / 151,
         // 2048^2 200 / 185, 4096 x 1024 247 / 181, 4096 x 2048 280 / 233, fp64 8192 x 1024 133 / 117, 2048 x 512 110 / 96 -> from 1 Mi cells
         // and 512 rows.  Lattices
         // narrower than 2048 (few strips, not measured) keep the earlier 3072^2 rule.
         const long long cells_plan = (long long)p->nx * ny_plan;
-        const bool stream_pays = p->nx >= 2048 ? (slab ? cells_plan >= (1LL << 20) && ny_plan >= 512 : cells_plan >= (8LL << 20))
+        const bool stream_pays = p->nx >= 2048 ? (slab ? cells_plan >= (1LL << 20) && ny_plan >= 512 : cells_plan >= ((c->es == 8 ? 4LL : 8LL) << 20))
                                                : cells_plan >= 3072LL * 3072;
         c->stream = can_stream && (p->kernel == LBM_KERNEL_STREAM || (p->kernel == LBM_KERNEL_AUTO && stream_pays));
         if (c->stream) {
