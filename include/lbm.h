@@ -202,7 +202,10 @@ int lbm_get_tau(lbm_ctx* c, void* tau_host, int host_dtype);
  *     lbm_halo_export_rows(side, S) -> transport -> lbm_halo_import_rows(side, S)      (lbm_halo_rows_elems(S) elements)
  * -- then lbm_step_unit(S) advances the slab S steps with no further communication: the frame passes recompute a shrinking
  * band of the neighbour's rows.  lbm_step_unit is exactly the launch sequence lbm_step uses between ranks (same kernels,
- * streams and events), minus the RCCL calls; lbm_step = this protocol with the transport inside. */
+ * streams and events), minus the RCCL calls; lbm_step = this protocol with the transport inside.
+ * Limits: 1 <= nrows <= 9 (a lattice carries 10 ghost rows per side; the tenth serves the recomputation of the lagged fields) and
+ * nrows <= ny_local; unit_steps = 3 .. the context's steps per launch (at most 8; exactly 2 for tb_steps = 2), and lbm_next_unit
+ * never plans a unit shorter than 4 on a slab. */
 int lbm_halo_elems(const lbm_ctx* c);
 int lbm_halo_export(lbm_ctx* c, int side, void* buf);
 int lbm_halo_import(lbm_ctx* c, int side, const void* buf);

@@ -198,6 +198,37 @@ Batch<R> batch_of(const lbm_ctx* c) {
     return Batch<R>{c->bstride, c->batch > 1 ? (const Relax<R>*)c->relax_dev : nullptr};
 }
 
+// Scratch lattices lat[2 .. 2 + n) of the frame passes, allocated on first use: the fused frame passes keep their
+// intermediate results in LDS windows whenever those fit, so the default fp32 / fp64 paths never touch a scratch lattice and a
+// streaming context holds 2 lattices (3 once the lagged fields have been asked for) instead of 2 + 7 -- 8192^2 fp64: 9.7 GB instead
+// of 48.  Only frame_beside, LBM_FLAG_FRAME_UNFUSED / NO_FRAME_LDS, windows that do not fit, and the replay of the lagged lattice
+// by single steps go through them.  Zeroed like the lattices themselves (dead reads of ghost positions see numbers); the wait makes
+// the memory safe for either stream, once per lattice and context.
+int ensure_scratch(lbm_ctx* c, int n) {
+    bool fresh = false;
+    for (int i = 2; i < 2 + n && i < LAT_LAG; ++i) {
+        if (c->lat[i]) continue;
+        hipError_t e = hipMalloc(&c->lat[i], c->lat_bytes);
+        if (e != hipSuccess) {
+            c->lat[i] = nullptr;
+            return fail(c, LBM_ERR_NOMEM, std::string("hipMalloc(scratch lattice of the frame passes): ") + hipGetErrorString(e));
+        }
+        HIP_TRY(c, hipMemsetAsync(c->lat[i], 0, c->lat_bytes, c->s_compute));
+        fresh = true;
+    }
+    if (fresh) HIP_TRY(c, hipStreamSynchronize(c->s_compute));
+    return LBM_OK;
+}
+
+// output lattices of the S frame passes lat[from] -> lat[to]: the scratch lattices (null when never needed, see ensure_scratch), then lat[to]
+template <typename R>
+FramePtrs<R> frame_ptrs(const lbm_ctx* c, int from, int to, int S) {
+    FramePtrs<R> fp;
+    fp.src = (const R*)c->lat[from];
+    for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+    return fp;
+}
+
 dim3 grid_rows(const lbm_ctx* c, int nrows) { return dim3((c->geo.nx + BLK - 1) / BLK, nrows, c->batch); }
 
 // Run-time parameters -> compile-time kernel variant (real type, collision operator, semantics, Smagorinsky).
@@ -293,14 +324,17 @@ bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows, int extra = 0, long
 
 // extra: rows of the neighbours' side that the row strips own on top of the slab's (see frame_passes)
 int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool lo, bool hi, int extra = 0) {
+    const bool beside = c->frame_beside && !lo && !hi && c->batch == 1;
+    if (beside || !frame_lds_fits(c, S, lo || hi, extra)) {
+        const int rc = ensure_scratch(c, S - 1);
+        if (rc) return rc;
+    }
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
-        FramePtrs<R> fp;
-        fp.src = (const R*)c->lat[from];
-        for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+        const FramePtrs<R> fp = frame_ptrs<R>(c, from, to, S);
         const int F = c->tb_f, L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
-        if (c->frame_beside && !lo && !hi && c->batch == 1) {
+        if (beside) {
             hipLaunchKernelGGL((k_frame_beside<R, VT::COLL, VT::SEM, VT::TURB>), dim3(2 * nsegx + 2 * nsegy), dim3(BLK), 0, s, fp, c->geo, relax_of<R>(c->p), F, S,
                                nsegx, nsegy, L);
             return;
@@ -367,19 +401,22 @@ StreamPlan plan_stream(const lbm_ctx* c, int S) {
 }
 
 int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_frame) {
+    const bool use_lds = frame_lds_fits(c, S, false, 0, ST_LDS_BYTES);
+    if (with_frame && !use_lds) {
+        const int rc = ensure_scratch(c, S - 1);
+        if (rc) return rc;
+    }
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
         const int F = c->tb_f, xe = c->geo.nx - F, ye = c->geo.ny - F;
         const StreamPlan pl = plan_stream(c, S);
-        FramePtrs<R> fp;
-        fp.src = (const R*)c->lat[from];
-        for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+        const FramePtrs<R> fp = frame_ptrs<R>(c, from, to, S);
         const int L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
         const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
         hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(nframe + pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s,
                            (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, F, xe, ye, pl.nstrips, pl.H,
-                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, ST_LDS_BYTES) ? 1 : 0, 0, 0, 0, c->xcd_bands ? 1 : 0);
+                           fp, nframe, nsegx, nsegy, L, use_lds ? 1 : 0, 0, 0, 0, c->xcd_bands ? 1 : 0);
     });
     HIP_TRY(c, hipGetLastError());
     return LBM_OK;
@@ -391,21 +428,24 @@ int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_
 // streaming segment that starts in the neighbour's rows of the deep halo.  It writes every row the next exchange sends.
 // extra: rows of the neighbours' side owned on top (1 for the lagged lattice, see frame_passes).
 int launch_stream_edges(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool lo, bool hi, int extra) {
+    const bool use_lds = frame_lds_fits(c, S, false, extra, ST_LDS_BYTES);
+    if (!use_lds) {
+        const int rc = ensure_scratch(c, S - 1);
+        if (rc) return rc;
+    }
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
         const int F = c->tb_f, xe = c->geo.nx - F, ye = c->geo.ny - F;
         const StreamPlan pl = plan_stream(c, S);
-        FramePtrs<R> fp;
-        fp.src = (const R*)c->lat[from];
-        for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+        const FramePtrs<R> fp = frame_ptrs<R>(c, from, to, S);
         const int bands = (lo ? 1 : 0) | (hi ? 2 : 0);
         const int ybeg = lo ? -extra : F, yend = hi ? c->geo.ny + extra : c->geo.ny - F;
         const int L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (yend - ybeg + L - 1) / L;
         const int nframe = 2 * nsegx + 2 * nsegy;
         hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(nframe + pl.nstrips * ((lo ? 1 : 0) + (hi ? 1 : 0))), dim3(ST_NT), 0, s,
                            (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, F, xe, ye, pl.nstrips, pl.H,
-                           fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, extra, ST_LDS_BYTES) ? 1 : 0, lo ? 1 + extra : 0,
+                           fp, nframe, nsegx, nsegy, L, use_lds ? 1 : 0, lo ? 1 + extra : 0,
                            hi ? 1 + extra : 0, bands, 0);
     });
     HIP_TRY(c, hipGetLastError());
@@ -420,9 +460,7 @@ int warm_stream(lbm_ctx* c) {
         using VT = decltype(v);
         using R = typename VT::R;
         const int F = c->tb_f;
-        FramePtrs<R> fp;
-        fp.src = (const R*)c->lat[0];
-        for (int i = 0; i < 8; ++i) fp.pass[i] = (R*)c->lat[1];
+        const FramePtrs<R> fp = frame_ptrs<R>(c, 0, 1, 1);
         hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
                            c->geo, relax_of<R>(c->p), c->tb_steps, F, c->geo.nx - F, /*ye=*/F, 1, 1, fp, 0, 1, 1, c->frame_seg, 0, 0, 0, 0, 0);
     });
@@ -437,6 +475,12 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
     // (profiles/r02_logs/tail_tiles.log)
     const bool tail = c->stream && c->tail_tiles && with_frame && steps >= 3 && steps <= 5;
     if (c->stream && !tail) return launch_stream(c, from, to, s, steps, with_frame);
+    const int S_tile = steps >= 3 ? (steps == 4 || steps == 5 ? steps : 3) : 2;
+    const bool tile_frame_lds = frame_lds_fits(c, S_tile, false, 0, TILE_FRAME_LDS_BYTES);
+    if (with_frame && steps >= 3 && !tile_frame_lds) {
+        const int rc = ensure_scratch(c, S_tile - 1);
+        if (rc) return rc;
+    }
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
@@ -448,14 +492,12 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
                 constexpr bool WIDE = decltype(wide)::value;
                 constexpr int PVC = WIDE ? 32 : 16, RV = (S - 1 + V - 1) / V, TX = (PVC - 2 * RV) * V, TY = 512 / PVC - 2 * (S - 1);
                 const int ntx = (xe - F + TX - 1) / TX, nty = (ye - F + TY - 1) / TY;
-                FramePtrs<R> fp;
-                fp.src = (const R*)c->lat[from];
-                for (int i = 0; i < 8; ++i) fp.pass[i] = i < S - 1 ? (R*)c->lat[2 + i] : (R*)c->lat[to];
+                const FramePtrs<R> fp = frame_ptrs<R>(c, from, to, S);
                 const int L = c->frame_seg, nsegx = (c->geo.nx + L - 1) / L, nsegy = (c->geo.ny - 2 * F + L - 1) / L;
                 const int nframe = with_frame ? 2 * nsegx + 2 * nsegy : 0;
                 hipLaunchKernelGGL((k_stepS_deep<R, VT::COLL, VT::SEM, S, WIDE, VT::TURB>), dim3(nframe + ntx * nty, c->batch), dim3(512), 0, s,
                                    (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), batch_of<R>(c), F, xe, ye, ntx, ntx * nty,
-                                   fp, nframe, nsegx, nsegy, L, frame_lds_fits(c, S, false, 0, TILE_FRAME_LDS_BYTES) ? 1 : 0);
+                                   fp, nframe, nsegx, nsegy, L, tile_frame_lds ? 1 : 0);
             };
             {   // (fp64: the x rim of S >= 4 is two vectors wide)
                 if (steps == 4) { go(std::integral_constant<int, 4>{}, std::false_type{}); return; }
@@ -741,8 +783,10 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     } else if (c->frame_fused && S >= 3 && (!slab || deep)) {
         rc = launch_frame_multi(c, a, b, S, c->s_comm, deep && has_lo, deep && has_hi);
         if (rc) return rc;
-    } else
-    for (int i = 1; i <= S; ++i) {
+    } else {
+      rc = ensure_scratch(c, 2);
+      if (rc) return rc;
+      for (int i = 1; i <= S; ++i) {
         const int to = i == S ? b : 2 + ((i - 1) & 1);
         const int ext = deep ? S - i : 0;
         rc = launch_frame(c, from, to, c->tb_f + S - i, c->s_comm, has_lo ? ext : 0, has_hi ? ext : 0);
@@ -752,6 +796,7 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
             if (rc) return rc;
         }
         from = to;
+      }
     }
     HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
     rc = launch_deep(c, a, b, c->s_compute, S);
@@ -822,7 +867,7 @@ int prev_lattice(lbm_ctx* c, int* which) {
             if (c->frame_fused && c->stream && c->deep_halo) rc = launch_stream_edges(c, from, LAT_LAG, c->s_compute, k, lo, hi, 1);
             else if (c->frame_fused) rc = launch_frame_multi(c, from, LAT_LAG, k, c->s_compute, lo, hi, 1);
             else {
-                rc = LBM_OK;
+                rc = ensure_scratch(c, 2);
                 int f = from;
                 for (int i = 1; i <= k && rc == LBM_OK; ++i) {
                     const int to = i == k ? LAT_LAG : 2 + ((i - 1) & 1);
@@ -835,6 +880,7 @@ int prev_lattice(lbm_ctx* c, int* which) {
         if (rc) return rc;
     } else {                            // k single steps (a lone lattice), through scratch lattice 2
         if (slab) return fail(c, LBM_ERR_STATE, "internal: the last unit of a slab cannot be replayed");
+        if (k > 1 && (rc = ensure_scratch(c, 2)) != LBM_OK) return rc;
         int f = from;
         for (int i = 1; i <= k; ++i) {
             const int to = i == k ? LAT_LAG : (f == 2 ? 3 : 2);
@@ -1055,7 +1101,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return bail("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
     if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return bail("a batch of lattices cannot be slab-decomposed");
     if (p->ny_local_min < 0 || p->ny_local_min > p->ny_local) return bail("ny_local_min must be 0 or the smallest ny_local of all ranks (<= ny_local)");
-    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > ST_MAX_S)) return bail("tb_steps must be 0 (default) or 2 .. 8");
+    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > ST_MAX_S)) return bail("tb_steps must be 0 (default) or 2 .. " + std::to_string(ST_MAX_S));
     if (p->frame_seg != 0 && p->frame_seg < 8) return bail("frame_seg must be 0 (default) or >= 8");
     if ((p->flags & LBM_FLAG_NT_ON) && (p->flags & LBM_FLAG_NT_OFF)) return bail("LBM_FLAG_NT_ON and LBM_FLAG_NT_OFF exclude each other");
     int ndev = 0;
@@ -1183,7 +1229,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
                 c->frame_beside = (rs + 7) / 8 * 8 * 4 + (rf + 7) / 8 * 8 <= 512;
             }
         } else {
-            if (want > 5) return (delete c, bail("tb_steps 6 .. 8 need kernel = STREAM"));
+            if (want > 5) return (delete c, bail("tb_steps 6 .. " + std::to_string(ST_MAX_S) + " need kernel = STREAM"));
             c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
             c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
         }
@@ -1243,8 +1289,8 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
     if ((e = hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
-    // scratch lattices of the frame passes: one per pass but the last (the fused frame kernel), at least the ping-pong pair
-    for (int i = 0; i < (c->use_tb ? (c->tb_steps == 2 ? 3 : 2 + std::max(2, c->tb_steps - 1)) : (c->push ? 3 : 2)); ++i) {
+    // the two lattices (+ ftemp of the push scheme); the scratch lattices of the frame passes come on first use (ensure_scratch)
+    for (int i = 0; i < (c->push ? 3 : 2); ++i) {
         if ((e = hipMalloc(&c->lat[i], bytes)) != hipSuccess) return cleanup(std::string("hipMalloc(lattice): ") + hipGetErrorString(e));
         // on the compute stream: the streams are non-blocking, a null-stream memset would race with the kernels
         if ((e = hipMemsetAsync(c->lat[i], 0, bytes, c->s_compute)) != hipSuccess) return cleanup(std::string("hipMemset: ") + hipGetErrorString(e));
@@ -1374,11 +1420,14 @@ int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
         for (int s = 1; s <= S; ++s) per += (32 - 2 * (s - 1)) / 4 + ((32 - 2 * (s - 1)) % 4 ? 1 : 0);
         wave_updates = wgs * per;
     }
+    int nlat = 0;                          // device lattices held now (2 + scratch lattices in use + the lagged one): footprint = nlat * lattice_bytes
+    for (int i = 0; i < NLAT; ++i) nlat += c->lat[i] ? 1 : 0;
     const int n = std::snprintf(buf, len, "kernel=%s steps_per_launch=%d frame=%d stream=%d vec=%d nt=%d deep_halo=%d frame_fused=%d lazy_lag=%d "
-                                "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d frame_beside=%d frame_seg=%d",
+                                "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d frame_beside=%d frame_seg=%d "
+                                "lattices=%d lattice_bytes=%lld",
                                 kern, S, c->use_tb ? c->tb_f : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
                                 c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->geo.row != c->geo.pitch ? "rows" : "planes", wgs, wave_updates, V,
-                                is_slab(c) ? 1 : 0, c->frame_beside ? 1 : 0, c->frame_seg);
+                                is_slab(c) ? 1 : 0, c->frame_beside ? 1 : 0, c->frame_seg, nlat, (long long)c->lat_bytes);
     return n < 0 ? LBM_ERR_INVALID : (n >= (int)len ? (int)len - 1 : n);
 }
 
@@ -1529,7 +1578,8 @@ long long lbm_halo_rows_elems(const lbm_ctx* c, int nrows) {
 namespace {
 int copy_rows(lbm_ctx* c, int side, int nrows, void* buf, bool out) {
     if (!c || !buf || (side != LBM_SIDE_LOW && side != LBM_SIDE_HIGH) || nrows < 1 || nrows >= GHY || nrows > c->geo.ny)
-        return fail(c, LBM_ERR_INVALID, "lbm_halo_export_rows / lbm_halo_import_rows: bad argument (1 <= nrows <= 5)");
+        return fail(c, LBM_ERR_INVALID, "lbm_halo_export_rows / lbm_halo_import_rows: bad argument (1 <= nrows <= " + std::to_string(GHY - 1) +
+                                        ", the ghost rows of a lattice, and <= ny_local)");
     if (c->batch > 1) return fail(c, LBM_ERR_STATE, "a batch of lattices has no slab halos");
     HIP_TRY(c, hipSetDevice(c->p.device));
     const RowBlocks b = deep_blocks(c, c->cur, out ? deep_send_row0(c, side, nrows) : deep_recv_row0(c, side, nrows), nrows);
@@ -1553,7 +1603,10 @@ int lbm_step_unit(lbm_ctx* c, int S) {
     if (own_transport(c)) return fail(c, LBM_ERR_STATE, "lbm_step_unit: a communicator is attached, lbm_step() moves the halos itself");
     if (c->raw[c->cur]) return fail(c, LBM_ERR_STATE, "lbm_step_unit: the first step after an upload is a single step");
     const bool ok = c->tb_steps == 2 ? S == 2 : (S >= 3 && S <= c->tb_steps);
-    if (!ok) return fail(c, LBM_ERR_INVALID, "lbm_step_unit: unit_steps must be 3 .. the context's steps per launch (lbm_next_unit)");
+    if (!ok)
+        return fail(c, LBM_ERR_INVALID, c->tb_steps == 2 ? std::string("lbm_step_unit: this context runs units of 2 steps")
+                                                         : "lbm_step_unit: unit_steps must be 3 .. " + std::to_string(c->tb_steps) +
+                                                               " (this context's steps per launch; lbm_next_unit plans 4 or more on a slab)");
     if (is_slab(c) && !c->deep_halo) return fail(c, LBM_ERR_STATE, "lbm_step_unit on a slab needs the deep halo (MRT_GPU semantics)");
     bool comm_used = false;
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));   // everything enqueued so far, the imported rows included
@@ -1596,35 +1649,49 @@ int lbm_comm_init(lbm_ctx* c, int nranks, int rank, const void* uid128) {
         const int32_t mine[NW] = {LBM_ABI_VERSION, c->p.nx, c->p.ny, c->p.dtype, c->p.semantics, c->p.turb, c->geo.pitch,
                                   c->geo.row != c->geo.pitch ? 1 : 0, c->use_tb ? (c->stream ? 2 : 1) : 0, c->tb_steps, c->tb_f, c->deep_halo ? 1 : 0,
                                   c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->p.collision, c->p.arith};
+        // (UNEXECUTED ON HARDWARE until a run with two GPUs exists: every box so far had one.)  The three blocks [mine | from LOW | from
+        // HIGH] are built on the host and uploaded by ONE synchronous copy, so nothing on the null stream can race with the receives
+        // that s_comm (a non-blocking stream) enqueues below; a failed send / receive still closes the RCCL group, and every failure
+        // path gives the communicator back.
+        auto drop_comm = [&] { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; c->nranks = 1; c->rank = 0; };
+        int32_t host[3 * NW];
+        std::memcpy(host, mine, sizeof(mine));
+        std::memset(host + NW, 0xff, 2 * NW * sizeof(int32_t));
         int32_t* dev = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&dev, 3 * NW * sizeof(int32_t)));
-        hipError_t e = hipMemcpy(dev, mine, sizeof(mine), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(dev + NW, 0xff, 2 * NW * sizeof(int32_t));
-        if (e != hipSuccess) { (void)hipFree(dev); return fail(c, LBM_ERR_HIP, std::string("lbm_comm_init: ") + hipGetErrorString(e)); }
-        ncclResult_t r = rccl().GroupStart();
-        for (int side = 0; side < 2 && r == ncclSuccess; ++side) {
-            if (!has_neighbour(c, side)) continue;
-            const int peer = side == LBM_SIDE_LOW ? rank - 1 : rank + 1;
-            r = rccl().Send(dev, NW, ncclInt32, peer, c->comm, c->s_comm);
-            if (r == ncclSuccess) r = rccl().Recv(dev + (1 + side) * NW, NW, ncclInt32, peer, c->comm, c->s_comm);
+        hipError_t e = hipMalloc((void**)&dev, sizeof(host));
+        if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            if (dev) (void)hipFree(dev);
+            drop_comm();
+            return fail(c, LBM_ERR_HIP, std::string("lbm_comm_init (plan check): ") + hipGetErrorString(e));
         }
-        if (r == ncclSuccess) r = rccl().GroupEnd();
+        ncclResult_t r = rccl().GroupStart();
+        if (r == ncclSuccess) {
+            for (int side = 0; side < 2 && r == ncclSuccess; ++side) {
+                if (!has_neighbour(c, side)) continue;
+                const int peer = side == LBM_SIDE_LOW ? rank - 1 : rank + 1;
+                r = rccl().Send(dev, NW, ncclInt32, peer, c->comm, c->s_comm);
+                if (r == ncclSuccess) r = rccl().Recv(dev + (1 + side) * NW, NW, ncclInt32, peer, c->comm, c->s_comm);
+            }
+            const ncclResult_t r_end = rccl().GroupEnd();   // (always: a group left open would swallow every later RCCL call)
+            if (r == ncclSuccess) r = r_end;
+        }
         int32_t theirs[2 * NW];
         if (r == ncclSuccess) {
             e = hipStreamSynchronize(c->s_comm);
             if (e == hipSuccess) e = hipMemcpy(theirs, dev + NW, sizeof(theirs), hipMemcpyDeviceToHost);
         }
         (void)hipFree(dev);
-        if (r != ncclSuccess) return fail(c, LBM_ERR_COMM, std::string("lbm_comm_init (plan check): ") + rccl().GetErrorString(r));
-        if (e != hipSuccess) return fail(c, LBM_ERR_HIP, std::string("lbm_comm_init (plan check): ") + hipGetErrorString(e));
+        if (r != ncclSuccess) { const std::string m = rccl().GetErrorString(r); drop_comm(); return fail(c, LBM_ERR_COMM, "lbm_comm_init (plan check): " + m); }
+        if (e != hipSuccess) { drop_comm(); return fail(c, LBM_ERR_HIP, std::string("lbm_comm_init (plan check): ") + hipGetErrorString(e)); }
         static const char* what[NW] = {"ABI version", "nx", "ny", "dtype", "semantics", "turb", "row pitch", "layout", "steps-per-launch path (0 none, 1 tile, 2 streaming kernel)",
                                        "steps per launch", "frame width", "deep halo", "fused frame", "lazy lag", "collision", "arith"};
         for (int side = 0; side < 2; ++side) {
             if (!has_neighbour(c, side)) continue;
             for (int i = 0; i < NW; ++i)
                 if (theirs[side * NW + i] != mine[i]) {
-                    (void)rccl().CommDestroy(c->comm);
-                    c->comm = nullptr; c->nranks = 1; c->rank = 0;
+                    drop_comm();
                     return fail(c, LBM_ERR_STATE, std::string("lbm_comm_init: rank ") + std::to_string(side == LBM_SIDE_LOW ? rank - 1 : rank + 1) +
                                                   " runs a different launch plan (" + what[i] + ": " + std::to_string(theirs[side * NW + i]) + " there, " +
                                                   std::to_string(mine[i]) + " here); create every rank with the same parameters and "

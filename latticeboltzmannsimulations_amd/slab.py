@@ -61,7 +61,7 @@ class _UnitDriver:
     def _steppers(self):
         raise NotImplementedError
 
-    def _plan(self, left):
+    def _plan(self, left, first=True):
         units = {_next_unit(st, left) for st in self._steppers()}
         if len(units) != 1:
             raise RuntimeError(f"the slabs disagree on the next launch unit ({sorted(units)}): create them with the same min_rows")
@@ -70,8 +70,10 @@ class _UnitDriver:
     def step(self, nsteps=1):
         left = int(nsteps)
         multi = self._nslabs() > 1
+        first = True
         while left > 0:
-            S = self._plan(left)
+            S = self._plan(left, first)
+            first = False
             if S > 1:
                 if multi:
                     self.exchange_rows(S)
@@ -166,8 +168,11 @@ class HaloDriver(_UnitDriver):
         self.lo, self.hi = neighbours(rank, world)
         self.send = {LOW: mk(), HIGH: mk()}
         self.recv = {LOW: mk(), HIGH: mk()}
+        self._rows = {}         # nrows -> (send, recv) buffers of the deep exchange, made once per unit length
         self._thin = False
         if world > 1:
+            self._agree(self._signature(), "launch plan (steps per launch, frame width, kernel path): create every slab with the same "
+                                           "parameters and min_rows")
             self.exchange()
 
     def _steppers(self):
@@ -176,13 +181,31 @@ class HaloDriver(_UnitDriver):
     def _nslabs(self):
         return self.world
 
-    def _plan(self, left):
+    def _signature(self):
+        """What shapes the unit sequence besides (steps left, raw): the plan items of lbm_describe (a stand-in stepper without
+        describe(): its steps per launch)."""
+        import zlib
+        if hasattr(self.st, "describe"):
+            d = self.st.describe()
+            d = d if isinstance(d, dict) else dict(kv.split("=", 1) for kv in str(d).split())
+            key = "|".join(f"{k}={d.get(k)}" for k in ("kernel", "steps_per_launch", "frame", "stream", "deep_halo", "frame_fused", "lazy_lag"))
+        else:
+            key = f"units={_next_unit(self.st, 1 << 20)}"
+        return zlib.crc32(key.encode())
+
+    def _agree(self, value, what):
+        t = self.torch.tensor([value, -value], dtype=self.torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        if int(t[0]) != value or int(-t[1]) != value:
+            raise RuntimeError(f"the ranks disagree on the {what}")
+
+    def _plan(self, left, first=True):
+        # The unit sequence of a call is a pure function of (launch plan, steps of the call, raw lattice or not): the plan was compared
+        # once in __init__, so ONE all-reduce per step() call -- on the first unit, which carries the other two -- keeps the ranks'
+        # send / receive sequences matched; nothing sits between the units of a call (ADVICE r02).
         S = _next_unit(self.st, left)
-        if self.world > 1:     # every rank must take the same unit: they post matching sends / receives
-            t = self.torch.tensor([S, -S], dtype=self.torch.int64, device=self.device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-            if int(t[0]) != S or int(-t[1]) != S:
-                raise RuntimeError("the ranks disagree on the next launch unit: create every slab with the same min_rows")
+        if first and self.world > 1:
+            self._agree((int(left) << 8) | S, "next launch unit: create every slab with the same min_rows and step them together")
         return S
 
     def _move(self, send, recv, export, imp):
@@ -210,9 +233,11 @@ class HaloDriver(_UnitDriver):
         self._thin = True
 
     def exchange_rows(self, nrows):
-        n = self.st.halo_rows_elems(nrows)
-        mk = lambda: self.torch.empty(n, dtype=self.tdt, device=self.device)  # noqa: E731
-        send, recv = {LOW: mk(), HIGH: mk()}, {LOW: mk(), HIGH: mk()}
+        if nrows not in self._rows:
+            n = self.st.halo_rows_elems(nrows)
+            mk = lambda: self.torch.empty(n, dtype=self.tdt, device=self.device)  # noqa: E731
+            self._rows[nrows] = ({LOW: mk(), HIGH: mk()}, {LOW: mk(), HIGH: mk()})
+        send, recv = self._rows[nrows]
         self._move(send, recv, lambda side, ptr: self.st.halo_export_rows(side, nrows, ptr),
                    lambda side, ptr: self.st.halo_import_rows(side, nrows, ptr))
 

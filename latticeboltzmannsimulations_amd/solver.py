@@ -72,7 +72,7 @@ class CavitySolver:
                    in factored form, about half the arithmetic, agrees to rounding)
     min_rows     : slabs: the smallest ny_local of ALL slabs of the decomposition (lbm_params.ny_local_min) -- the launch plan is
                    derived from it, so that neighbours run the same exchange protocol
-    tuning       : A/B switches of the launch plan, none of which changes a result: tb_steps (2..5 steps per launch),
+    tuning       : A/B switches of the launch plan, none of which changes a result: tb_steps (2..5 steps per launch; 2..8 with kernel='stream'),
                    frame_seg, and the boolean flags deep_halo, frame_fused, frame_fused_batch, frame_lds, nt, comm_priority,
                    eager_lag, frame_beside, frame_wide, edge_first, edge_reserve, xcd_bands, tail_tiles (lbm_params.tb_steps / frame_seg / flags)
     """
@@ -353,7 +353,7 @@ def _one_rccl():
     bundled one, else /opt/rocm's).  A process that created a communicator through the library and imported torch only AFTERWARDS
     aborted in the exit handlers ("double free or corruption") -- also with torch's own librccl.so mapped by path beforehand, so it
     is the order of initialisation of torch's bundled ROCm libraries that matters, not a second RCCL (measured:
-    tools/probes/order_test.py, profiles/r02_logs/rccl_order.log).  Where torch is installed it is therefore imported before the
+    tools/probes/order_probe.py, profiles/r02_logs/rccl_order.log).  Where torch is installed it is therefore imported before the
     first RCCL call; processes that use this path exchange the communicator id through torch.distributed anyway."""
     import importlib.util
     import sys

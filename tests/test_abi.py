@@ -143,3 +143,22 @@ def test_integration_md_binding_matches_the_struct():
     hdr = open(os.path.join(ROOT, "include", "lbm.h")).read()
     body = hdr[hdr.index("typedef struct lbm_params {"):hdr.index("} lbm_params;")]
     assert re.findall(r"^\s+(?:int32_t|double)\s+(\w+);", body, re.M) == ints + dbls
+
+
+def test_documented_limits_follow_the_source_constants():
+    """The limits that include/lbm.h and the error messages quote (rows of a deep halo, steps per launch) are derived from
+    GHY (lbm_device.hpp) and ST_MAX_S (lbm_stream.hpp), not typed in a second time ('1 <= nrows <= 5' had gone stale)."""
+    import re
+    csrc = os.path.join(ROOT, "latticeboltzmannsimulations_amd", "csrc")
+    dev = open(os.path.join(csrc, "lbm_device.hpp")).read()
+    st = open(os.path.join(csrc, "lbm_stream.hpp")).read()
+    ghy = int(re.search(r"constexpr int GHY = (\d+);", dev).group(1))
+    waves = int(re.search(r"constexpr int ST_WAVES = (\d+);", st).group(1))
+    assert re.search(r"constexpr int ST_MAX_S = ST_WAVES / 2;", st)
+    max_s = waves // 2
+    hdr = open(os.path.join(ROOT, "include", "lbm.h")).read()
+    assert f"1 <= nrows <= {ghy - 1}" in hdr and f"carries {ghy} ghost rows" in hdr
+    assert f"(at most {max_s};" in hdr and f"STREAM: 2 .. {max_s}" in hdr
+    src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith(".hip"))
+    assert "std::to_string(GHY - 1)" in src and "std::to_string(ST_MAX_S)" in src
+    assert not re.search(r"<= nrows <= \d", src), "a literal row limit in an error message"
