@@ -74,14 +74,23 @@ def relaxation(Re, ny_global, uLB=0.08, omega_eps=1.2, omega_q=1.2):
     return dict(omega=omega, omegam=omegam, omega_e=1.0, omega_eps=omega_eps, omega_q=omega_q)
 
 
-def equ(rho, ux, uy, t):
-    """a3: MRT.py:213-231 (association per Python precedence); returns feq[9, ...]."""
+def equ(rho, ux, uy, t, promote=False):
+    """a3: MRT.py:213-231 (association per Python precedence); returns feq[9, ...].
+
+    promote (the CUDA text, MRT_GPU.py:410,652: `rho_l*t_g[k]*(1. + 3.0*cu + 9*0.5*cu*cu - 3.0*0.5*usqr)`): `rho_l*t_g[k]` is a
+    float product; the `double` literals make the bracket, and its product with that float, double operations (C's usual arithmetic
+    conversions); the store rounds ONCE to the lattice type.  On an fp64 lattice this is the plain evaluation."""
     R = rho.dtype.type
     usqr = ux * ux + uy * uy
     feq = np.empty((9,) + rho.shape, dtype=rho.dtype)
     for k in range(9):
         cu = int(CX[k]) * ux + int(CY[k]) * uy
-        feq[k] = (rho * t[k]) * (((R(1.) + R(3.0) * cu) + (R(4.5) * cu) * cu) - R(1.5) * usqr)
+        if promote:
+            D = np.float64
+            cud, rt = cu.astype(D), (rho * t[k]).astype(D)
+            feq[k] = (rt * (((D(1.) + D(3.0) * cud) + (D(4.5) * cud) * cud) - D(1.5) * usqr.astype(D))).astype(rho.dtype)
+        else:
+            feq[k] = (rho * t[k]) * (((R(1.) + R(3.0) * cu) + (R(4.5) * cu) * cu) - R(1.5) * usqr)
     return feq
 
 
@@ -89,8 +98,13 @@ class CavityOracle:
     """Whole-domain stepper on reference-layout arrays fin[9, X, Y]."""
 
     def __init__(self, nx, ny, Re, uLB=0.08, semantics="mrt_py", collision="SRT",
-                 dtype=np.float64, omega_eps=None, omega_q=None, ny_global=None, turb=0):
+                 dtype=np.float64, omega_eps=None, omega_q=None, ny_global=None, turb=0, promote=False):
+        """promote: the sub-expressions of MRT_GPU.py's CUDA text that carry `double` literals (lines 385, 410, 638-642, 652) are
+        evaluated in double and rounded once to the lattice type -- what C's usual arithmetic conversions prescribe for that text;
+        everything else stays an operation of the lattice type.  (nvcc's default FMA contraction is a further, unknowable, step.)"""
         assert semantics in ("mrt_py", "mrt_gpu") and collision in ("SRT", "TRT", "MRT")
+        assert not (promote and semantics != "mrt_gpu"), "promotion is a property of MRT_GPU.py's CUDA text"
+        self.promote = bool(promote)
         assert not (turb and semantics == "mrt_py"), "the Smagorinsky closure exists only in MRT_GPU.py"
         self.turb = int(turb)
         self.nx, self.ny, self.uLB = nx, ny, uLB
@@ -112,7 +126,7 @@ class CavityOracle:
         self.u = np.zeros((2, nx, ny), dtype=dtype)
         iv = np.zeros((2, nx, ny), dtype=dtype)
         iv[0, :, 0] = uLB
-        self.fin = equ(self.rho, iv[0], iv[1], self.t)
+        self.fin = equ(self.rho, iv[0], iv[1], self.t, self.promote)
         self.feq = self.fin.copy()          # feq_g starts as a copy of fin (MRT_GPU.py:325)
         self.fpost = self.fin.copy()
         self.nsteps = 0
@@ -141,6 +155,13 @@ class CavityOracle:
         p1 = -f[8] + (f[7] + (-f[6] + f[5]))
         p2 = -feq_prev[8] + (feq_prev[7] + (-feq_prev[6] + feq_prev[5]))
         q = p1 - p2
+        if self.promote:
+            # MRT_GPU.py:385: tau*tau (float * float), Cs2 = 0.025f and abs(Qmf) are floats; 18*1.4142 is a double constant and
+            # makes the rest double: one rounding at `tau =`
+            D = np.float64
+            tau = (D(0.5) * (D(tau0) + np.sqrt(D(tau0 * tau0) + ((D(18 * 1.4142) * D(R(0.025))) * np.abs(q).astype(D))
+                                               / rho_prev.astype(D)))).astype(self.dtype)
+            return R(1.0) / tau
         tau = R(0.5) * (tau0 + np.sqrt(tau0 * tau0 + ((R(18 * 1.4142) * R(0.025)) * np.abs(q)) / rho_prev))
         return R(1.0) / tau
 
@@ -185,6 +206,14 @@ class CavityOracle:
         meq[6] = -jy + R(3.0) * ((jy * jy) * jy)
         meq[7] = jx * jx - jy * jy
         meq[8] = jx * jy
+        if self.promote:
+            # MRT_GPU.py:638-642: the literals -2.0, 3.0, 9.0 make the sums double; products of jx, jy among themselves stay float
+            D, dt = np.float64, self.dtype
+            s2, p4 = jx * jx + jy * jy, ((jx * jx) * jy) * jy
+            meq[1] = (D(-2.0) * rho.astype(D) + D(3.0) * s2.astype(D)).astype(dt)
+            meq[2] = ((D(-3.0) * s2.astype(D) + rho.astype(D)) + D(9.0) * p4.astype(D)).astype(dt)
+            meq[4] = ((-jx).astype(D) + D(3.0) * ((jx * jx) * jx).astype(D)).astype(dt)
+            meq[6] = ((-jy).astype(D) + D(3.0) * ((jy * jy) * jy).astype(D)).astype(dt)
         wv = list(self.omega_vec)
         wv[7] = wv[8] = w_nu
         for k in range(9):
@@ -252,7 +281,7 @@ class CavityOracle:
         for _ in range(n):
             w_nu = self.smagorinsky_omega(self.fin, self.feq, self.rho) if self.turb else None
             rho, ux, uy = self.macros(self.fin)
-            feq = equ(rho, ux, uy, self.t)
+            feq = equ(rho, ux, uy, self.t, self.promote)
             fpost = self.collide(self.fin, rho, feq, w_nu)
             self.stream(self.fin, fpost)
             self.wall_bc(self.fin, feq)
@@ -268,7 +297,7 @@ class CavityOracle:
         self.fin = np.array(fin, dtype=self.dtype, copy=True)
         self.nsteps = 0
         rho, ux, uy = self.macros(self.fin)
-        self.rho, self.feq = rho, equ(rho, ux, uy, self.t)
+        self.rho, self.feq = rho, equ(rho, ux, uy, self.t, self.promote)
 
     def peek_macros(self):
         """rho, u that the NEXT iteration would compute from the current fin."""

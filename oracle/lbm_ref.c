@@ -55,12 +55,26 @@ static const double MINV[9][9] = {
 enum { SEM_MRT_PY = 0, SEM_MRT_GPU = 1 };
 enum { COLL_SRT = 0, COLL_TRT = 1, COLL_MRT = 2 };
 
-/* a3: MRT.py:213-231 */
-static inline void equ_cell(REAL rho, REAL ux, REAL uy, const REAL t[9], REAL feq[9]) {
+/* PROMOTE (mrt_gpu semantics, float build): the CUDA text of MRT_GPU.py mixes `double` literals into `float` expressions
+ * (MRT_GPU.py:385, 410, 638-642, 652).  By C's usual arithmetic conversions every operation that has such a literal (or a
+ * value already promoted by one) as an operand is a double operation, and the sub-expression is rounded to float ONCE, at
+ * the assignment.  promote != 0 evaluates exactly those sub-expressions that way; operations between two floats (or an int
+ * and a float) stay float operations.  In the double build the casts are no-ops: promote changes nothing (tests assert it).
+ * What this still is NOT: nvcc's default --fmad=true may fuse any float multiply-add of the text into one FMA; which ones
+ * is the compiler's choice and cannot be read from the text, so no restatement can claim the bits of a real run. */
+
+/* a3: MRT.py:213-231; promote: MRT_GPU.py:410,652 `rho_l*t_g[k]*(1. + 3.0*cu + 9*0.5*cu*cu - 3.0*0.5*usqr)` --
+ * rho_l*t_g[k] is float * float, the bracket is double throughout, their product double, one rounding at the store */
+static inline void equ_cell(REAL rho, REAL ux, REAL uy, const REAL t[9], REAL feq[9], int promote) {
     REAL usqr = ux * ux + uy * uy;
     for (int k = 0; k < 9; ++k) {
         REAL cu = (REAL)CX[k] * ux + (REAL)CY[k] * uy;
-        feq[k] = (rho * t[k]) * ((((REAL)1. + (REAL)3.0 * cu) + ((REAL)4.5 * cu) * cu) - (REAL)1.5 * usqr);
+        if (promote) {
+            const REAL rt = rho * t[k];
+            feq[k] = (REAL)((double)rt * (((1. + 3.0 * (double)cu) + (4.5 * (double)cu) * (double)cu) - 1.5 * (double)usqr));
+        } else {
+            feq[k] = (rho * t[k]) * ((((REAL)1. + (REAL)3.0 * cu) + ((REAL)4.5 * cu) * cu) - (REAL)1.5 * usqr);
+        }
     }
 }
 
@@ -75,17 +89,24 @@ static inline void equ_cell(REAL rho, REAL ux, REAL uy, const REAL t[9], REAL fe
 
 /* Smagorinsky relaxation rate, MRT_GPU.py:368-387 (lines 370-373 are dead code: Cs2 is overwritten
  * at 374).  feq_prev / rho_prev: what funRT wrote in the previous step at this cell. */
-static inline REAL smagorinsky_omega(const REAL f[9], const REAL fe_prev[9], REAL rho_prev, REAL omega) {
-    const REAL tau0 = (REAL)1.0 / omega;
+static inline REAL smagorinsky_omega(const REAL f[9], const REAL fe_prev[9], REAL rho_prev, REAL omega, int promote) {
+    const REAL tau0 = (REAL)1.0 / omega;   /* (`1.0/omega` is a double division rounded to float = the float division: one operation) */
     const REAL p1 = -f[8] + (f[7] + (-f[6] + f[5]));
     const REAL p2 = -fe_prev[8] + (fe_prev[7] + (-fe_prev[6] + fe_prev[5]));
     const REAL q = p1 - p2;
+    if (promote) {
+        /* MRT_GPU.py:385 `0.5*(tau + sqrt( (tau*tau + ( 18*1.4142*Cs2*abs(Qmf) )/rho_g[i] ) ) )`: tau*tau is float * float, Cs2 is the
+         * float 0.025f, abs(float) is float; everything else is double (18*1.4142 is a double constant), one rounding at `tau =` */
+        const REAL tt = tau0 * tau0, cs2 = (REAL)0.025, aq = RABS(q);
+        const REAL tau = (REAL)(0.5 * ((double)tau0 + sqrt((double)tt + (((18 * 1.4142) * (double)cs2) * (double)aq) / (double)rho_prev)));
+        return (REAL)1.0 / tau;
+    }
     const REAL tau = (REAL)0.5 * (tau0 + RSQRT(tau0 * tau0 + (((REAL)(18 * 1.4142) * (REAL)0.025) * RABS(q)) / rho_prev));
     return (REAL)1.0 / tau;
 }
 
 static inline void collide_cell(int coll, const REAL f[9], REAL rho, const REAL feq[9], const REAL w[5],
-                                const REAL mi[9][9], REAL out[9]) {
+                                const REAL mi[9][9], REAL out[9], int promote) {
     if (coll == COLL_SRT) { /* MRT.py:396 */
         for (int k = 0; k < 9; ++k) out[k] = f[k] - w[0] * (f[k] - feq[k]);
     } else if (coll == COLL_TRT) { /* MRT_GPU.py:455-462,514-525 */
@@ -118,6 +139,14 @@ static inline void collide_cell(int coll, const REAL f[9], REAL rho, const REAL 
         meq[6] = -jy + (REAL)3.0 * ((jy * jy) * jy);
         meq[7] = jx * jx - jy * jy;
         meq[8] = jx * jy;
+        if (promote) {
+            /* MRT_GPU.py:638-642: the literals -2.0, 3.0, 9.0 make these sums double; the products of jx, jy among themselves are float */
+            const REAL s = jx * jx + jy * jy, p4 = ((jx * jx) * jy) * jy, x3 = (jx * jx) * jx, y3 = (jy * jy) * jy;
+            meq[1] = (REAL)(-2.0 * (double)rho + 3.0 * (double)s);
+            meq[2] = (REAL)((-3.0 * (double)s + (double)rho) + 9.0 * (double)p4);
+            meq[4] = (REAL)((double)(-jx) + 3.0 * (double)x3);
+            meq[6] = (REAL)((double)(-jy) + 3.0 * (double)y3);
+        }
         for (int k = 0; k < 9; ++k) m[k] = m[k] - wv[k] * (m[k] - meq[k]);
         for (int k = 0; k < 9; ++k) {
             REAL acc = mi[k][0] * m[0];
@@ -148,11 +177,12 @@ extern int lbmref_get_threads(void);
  * macroscopic fields computed in the LAST iteration (MRT.py:500-503 one-step lag).
  * Returns 0, or -1 on allocation failure / bad arguments. */
 int FN(lbmref_step)(REAL* fin, REAL* rho_out, REAL* u_out, int nx, int ny, int nsteps, int semantics,
-                    int collision, const double* relax, double uLB_d, int turb, REAL* feq_hist) {
+                    int collision, const double* relax, double uLB_d, int turb, REAL* feq_hist, int promote) {
     /* turb != 0: feq_hist[9][nx][ny] holds the previous step's equilibrium on entry (initially a
      * copy of fin, MRT_GPU.py:325) and rho_out the previous step's density (initially 1); both are
      * updated in place. */
     if (nx < 4 || ny < 4 || nsteps < 0 || (turb && (!feq_hist || semantics != SEM_MRT_GPU))) return -1;
+    if (promote && semantics != SEM_MRT_GPU) return -1;   /* MRT.py is NumPy fp64: nothing to promote */
     const size_t n = (size_t)nx * ny;
     REAL* fpost = (REAL*)malloc(9 * n * sizeof(REAL));
     REAL* feq = (REAL*)malloc(9 * n * sizeof(REAL));
@@ -189,10 +219,10 @@ int FN(lbmref_step)(REAL* fin, REAL* rho_out, REAL* u_out, int nx, int ny, int n
                 if (turb) {
                     REAL fp[9];
                     for (int k = 0; k < 9; ++k) fp[k] = F(feq_hist, k, x, y);
-                    wc[0] = smagorinsky_omega(f, fp, rho_out[(size_t)x * Y + y], w[0]);
+                    wc[0] = smagorinsky_omega(f, fp, rho_out[(size_t)x * Y + y], w[0], promote);
                 }
-                equ_cell(rho, ux, uy, t, fe);
-                collide_cell(collision, f, rho, fe, wc, mi, fo);
+                equ_cell(rho, ux, uy, t, fe, promote);
+                collide_cell(collision, f, rho, fe, wc, mi, fo, promote);
                 for (int k = 0; k < 9; ++k) { F(feq, k, x, y) = fe[k]; F(fpost, k, x, y) = fo[k]; }
                 rho_out[(size_t)x * Y + y] = rho;
                 u_out[(size_t)x * Y + y] = ux;
@@ -271,7 +301,7 @@ int FN(lbmref_step)(REAL* fin, REAL* rho_out, REAL* u_out, int nx, int ny, int n
 
 /* equilibrium of the macroscopic state (with wall overrides) of given populations: the
  * Smagorinsky history after a state upload (same convention as lbm_set_state) */
-int FN(lbmref_history)(const REAL* fin, REAL* rho_out, REAL* feq_hist, int nx, int ny, double uLB_d) {
+int FN(lbmref_history)(const REAL* fin, REAL* rho_out, REAL* feq_hist, int nx, int ny, double uLB_d, int promote) {
     const size_t n = (size_t)nx * ny;
     REAL t[9];
     t[0] = (REAL)(4.0 / 9.0);
@@ -286,15 +316,17 @@ int FN(lbmref_history)(const REAL* fin, REAL* rho_out, REAL* feq_hist, int nx, i
             REAL uy = (((((f[2] - f[4]) + f[5]) + f[6]) - f[7]) - f[8]) / rho;
             if (x == 0 || x == nx - 1 || y == ny - 1) { ux = 0; uy = 0; }
             if (y == 0) { rho = ((f[0] + f[1]) + f[3]) + (REAL)2. * ((f[2] + f[5]) + f[6]); ux = (REAL)uLB_d; uy = 0; }
-            equ_cell(rho, ux, uy, t, fe);
+            equ_cell(rho, ux, uy, t, fe, promote);
             for (int k = 0; k < 9; ++k) feq_hist[(size_t)k * n + (size_t)x * ny + y] = fe[k];
             rho_out[(size_t)x * ny + y] = rho;
         }
     return 0;
 }
 
-/* A.7 init: fin = equ(rho = 1, u = (uLB on the lid row, 0))  (MRT.py:206,260-268) */
-int FN(lbmref_init)(REAL* fin, int nx, int ny, double uLB_d) {
+/* A.7 init: fin = equ(rho = 1, u = (uLB on the lid row, 0))  (MRT.py:206,260-268).  promote: MRT_GPU.py:230-247 evaluates the same
+ * formula on the host with cu, usqr in float64 arrays and stores into float32 -- the bracket in double, one rounding -- which for
+ * rho = 1 is the device formula above (with the NumPy of 2017, float32 array * float64 scalar = float32: rho*t[i] is a float). */
+int FN(lbmref_init)(REAL* fin, int nx, int ny, double uLB_d, int promote) {
     const size_t n = (size_t)nx * ny;
     REAL t[9], fe[9];
     t[0] = (REAL)(4.0 / 9.0);
@@ -302,7 +334,7 @@ int FN(lbmref_init)(REAL* fin, int nx, int ny, double uLB_d) {
     for (int k = 5; k < 9; ++k) t[k] = (REAL)(1.0 / 36.);
     for (int x = 0; x < nx; ++x)
         for (int y = 0; y < ny; ++y) {
-            equ_cell((REAL)1, y == 0 ? (REAL)uLB_d : (REAL)0, (REAL)0, t, fe);
+            equ_cell((REAL)1, y == 0 ? (REAL)uLB_d : (REAL)0, (REAL)0, t, fe, promote);
             for (int k = 0; k < 9; ++k) fin[(size_t)k * n + (size_t)x * ny + y] = fe[k];
         }
     return 0;

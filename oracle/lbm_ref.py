@@ -32,13 +32,13 @@ def lib():
             f = getattr(_lib, "lbmref_step_" + suf)
             f.restype = ctypes.c_int
             f.argtypes = [p, p, p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                          ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_int, p]
+                          ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_int, p, ctypes.c_int]
             h = getattr(_lib, "lbmref_history_" + suf)
             h.restype = ctypes.c_int
-            h.argtypes = [p, p, p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+            h.argtypes = [p, p, p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
             g = getattr(_lib, "lbmref_init_" + suf)
             g.restype = ctypes.c_int
-            g.argtypes = [p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+            g.argtypes = [p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
         _lib.lbmref_set_threads.argtypes = [ctypes.c_int]
         _lib.lbmref_max_threads.restype = ctypes.c_int
     return _lib
@@ -62,8 +62,12 @@ class CavityOracleC:
     """Same interface as oracle.lbm_numpy.CavityOracle, backed by lbm_ref.c."""
 
     def __init__(self, nx, ny, Re, uLB=0.08, semantics="mrt_py", collision="SRT", dtype=np.float64,
-                 omega_eps=None, omega_q=None, ny_global=None, turb=0):
+                 omega_eps=None, omega_q=None, ny_global=None, turb=0, promote=False):
+        """promote: evaluate the sub-expressions of MRT_GPU.py's CUDA text that carry `double` literals in double and round once to
+        the lattice type (C's usual arithmetic conversions; lbm_ref.c, PROMOTE).  No effect on an fp64 lattice."""
         from .lbm_numpy import relaxation
+        assert not (promote and semantics != "mrt_gpu"), "promotion is a property of MRT_GPU.py's CUDA text"
+        self.promote = int(bool(promote))
         self.turb = int(turb)
         self.nx, self.ny, self.uLB = nx, ny, uLB
         self.sem, self.coll = semantics, collision
@@ -77,7 +81,7 @@ class CavityOracleC:
         self._suf = "f64" if self.dtype == np.float64 else "f32"
         self._ct = ctypes.c_double if self.dtype == np.float64 else ctypes.c_float
         self.fin = np.empty((9, nx, ny), dtype=self.dtype)
-        getattr(lib(), "lbmref_init_" + self._suf)(self._p(self.fin), nx, ny, uLB)
+        getattr(lib(), "lbmref_init_" + self._suf)(self._p(self.fin), nx, ny, uLB, self.promote)
         self.rho = np.ones((nx, ny), dtype=self.dtype)
         self.u = np.zeros((2, nx, ny), dtype=self.dtype)
         self.feq = self.fin.copy() if self.turb else None       # feq_g starts as a copy of fin (MRT_GPU.py:325)
@@ -90,7 +94,7 @@ class CavityOracleC:
         rc = getattr(lib(), "lbmref_step_" + self._suf)(
             self._p(self.fin), self._p(self.rho), self._p(self.u), self.nx, self.ny, int(n),
             SEM[self.sem], COLL[self.coll], self._w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self.uLB,
-            self.turb, self._p(self.feq) if self.turb else None)
+            self.turb, self._p(self.feq) if self.turb else None, self.promote)
         if rc != 0:
             raise RuntimeError("lbmref_step failed")
         self.nsteps += n
@@ -101,4 +105,4 @@ class CavityOracleC:
         self.nsteps = 0
         if self.turb:   # Smagorinsky history := equilibrium / density of the uploaded state
             getattr(lib(), "lbmref_history_" + self._suf)(self._p(self.fin), self._p(self.rho), self._p(self.feq),
-                                                          self.nx, self.ny, self.uLB)
+                                                          self.nx, self.ny, self.uLB, self.promote)

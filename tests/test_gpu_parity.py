@@ -667,6 +667,46 @@ def test_config_c3_4096_fp32_against_oracle(steps):
     assert np.abs(u - o.u).max() / 0.08 < 2e-4 and np.abs(rho - o.rho).max() < 2e-5
 
 
+def test_strict_fp32_path_against_the_promoted_oracle():
+    """VERDICT r02 "missing" item 1, quantified on the shipped path: MRT_GPU.py's CUDA text evaluates the sub-expressions that carry
+    `double` literals (lines 385, 410, 638-642, 652) in double and rounds once (oracle `promote=True`); the library computes fp32
+    lattices in fp32 throughout (== the plain oracle bit for bit, asserted here too).  Distance of the HIP strict fp32 path from the
+    PROMOTED oracle, the stated tolerance of that deviation: populations <= 1e-5 relative, u <= 5e-5 uLB after 1, 100, 1000 steps at
+    128 x 128 (MRT; SRT + closure = the reference script's default mode) and <= 1e-6 / 1e-5 on the C3 lattice after the 20 steps of
+    the driver's bench.  Measured values: DESIGN "Arithmetic contract" (a few 1e-6: a tenth of fp32's own distance from fp64)."""
+    n = 128
+    rows = []
+    for coll, turb in (("MRT", 0), ("SRT", 1)):
+        plain = CavityOracleC(n, n, 1000.0, semantics="mrt_gpu", collision=coll, dtype=np.float32, turb=turb)
+        prom = CavityOracleC(n, n, 1000.0, semantics="mrt_gpu", collision=coll, dtype=np.float32, turb=turb, promote=True)
+        with CavitySolver(n, n, 1000.0, RT=coll, dtype=np.float32, turb=turb) as s:
+            done = 0
+            for steps in (1, 100, 1000):
+                plain.step(steps - done); prom.step(steps - done); s.step(steps - done); done = steps
+                u, rho, fin = s.get_fields(want_fin=True)
+                assert np.array_equal(fin, plain.fin) and np.array_equal(u, plain.u)
+                df, du = np.abs(fin - prom.fin).max() / np.abs(prom.fin).max(), np.abs(u - prom.u).max() / 0.08
+                ulp = np.abs(fin.view(np.int32).astype(np.int64) - prom.fin.view(np.int32).astype(np.int64))
+                rows.append((coll, turb, steps, df, du, int(ulp.max()), float((ulp > 0).mean())))
+                assert df < 1e-5 and du < 5e-5, rows[-1]
+    n = 4096
+    set_threads(_threads())
+    try:
+        prom = CavityOracleC(n, n, 1000.0, semantics="mrt_gpu", collision="MRT", dtype=np.float32, promote=True).step(20)
+    finally:
+        set_threads(1)
+    with CavitySolver(n, n, 1000.0, RT="MRT", dtype=np.float32) as s:
+        s.step(20)
+        u, rho, fin = s.get_fields(want_fin=True)
+    df, du = np.abs(fin - prom.fin).max() / np.abs(prom.fin).max(), np.abs(u - prom.u).max() / 0.08
+    ulp = np.abs(fin.view(np.int32).astype(np.int64) - prom.fin.view(np.int32).astype(np.int64))
+    rows.append(("MRT C3 4096^2", 0, 20, df, du, int(ulp.max()), float((ulp > 0).mean())))
+    assert df < 1e-6 and du < 1e-5, rows[-1]
+    print("\npromotion gap (HIP strict fp32 vs promoted oracle): operator, closure, steps, max rel populations, max u / uLB, max ulp, share of differing words")
+    for r in rows:
+        print("  %-14s turb=%d %5d steps  %.3g  %.3g  %d ulp  %.4f" % r)
+
+
 def test_config_c4_8192_fp64_re3200_slabs_and_oracle():
     """BASELINE.json configs[3]: 8192 x 8192, Re = 3200, fp64, MRT, y-slabs for 8 GPUs.  On one device: the undivided lattice
     (default multi-step kernels) == the C oracle after 10 steps, == the one-step vector kernel, == 8 slabs of 8192 x 1024
@@ -841,9 +881,10 @@ def test_streaming_kernel_fast_arithmetic_every_instantiation(coll, turb, dtype)
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast", tuning=dict(tb_steps=8)) as s8, \
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast",
                          tuning=dict(tb_steps=3, frame_beside=True, tail_tiles=False)) as s3:
-        assert s8.next_unit(100) == 8 and s3.next_unit(100) == 3
         for n in calls:
             o.step(n); g.step(n); s8.step(n); s3.step(n)
+            # (the first unit of a freshly initialised lattice is a single step; from then on the streaming plan applies)
+            assert s8.next_unit(100) == 8 and s3.next_unit(100) == 3
             ref = g.get_fields(want_fin=True)
             for name, s in (("S=8", s8), ("S=3", s3)):
                 got = s.get_fields(want_fin=True)
