@@ -66,7 +66,7 @@ def host_cores():
     return int(os.environ.get("LBM_BENCH_CPU_THREADS", min(n, 32)))
 
 
-def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=15.0):
+def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=15.0, table_s=0.0):
     """The C oracle (oracle/lbm_ref.c, kind 'port') on this host's cores, bounded sample."""
     from oracle import lbm_ref
     threads = max(1, min(lbm_ref.max_threads(), host_cores()))
@@ -77,9 +77,40 @@ def cpu_baseline(nx, ny, Re, dtype, RT, semantics, budget_s=15.0):
     n = int(max(2, min(200, budget_s / max(one, 1e-6))))
     t = time.perf_counter(); o.step(n); dt = time.perf_counter() - t
     lbm_ref.set_threads(1)
-    return {"value": nx * ny * n / dt / 1e6, "unit": "MLUPS", "cores": threads, "kind": "port",
-            "sample": f"{n} steps of the same {nx}x{ny} {dtype} {RT} lattice with the C oracle (oracle/lbm_ref.c, "
-                      f"OpenMP, {threads} threads), {dt:.1f} s"}
+    out = {"value": nx * ny * n / dt / 1e6, "unit": "MLUPS", "cores": threads, "kind": "port",
+           "sample": f"{n} steps of the same {nx}x{ny} {dtype} {RT} lattice with the C oracle (oracle/lbm_ref.c, "
+                     f"OpenMP, {threads} threads), {dt:.1f} s"}
+    if table_s > 0:
+        out["table"] = cpu_baseline_table(nx, ny, Re, dtype, RT, semantics, table_s)
+    return out
+
+
+def cpu_baseline_table(nx, ny, Re, dtype, RT, semantics, budget_s=3.0):
+    """SURVEY 8(d)'s other CPU figures beside `value`, each bounded to about `budget_s` seconds: the C restatement on the same
+    lattice at 1 thread and at 4 (the count hard-coded in the reference's Cython path, functions.pyx:69), and the NumPy restatement
+    of MRT.py (its own semantics: SRT, fp64, 1 thread) at 1024^2 (MRT.py's pure-NumPy loop, MRT.py:286-453)."""
+    from oracle import lbm_ref
+    from oracle.lbm_numpy import CavityOracle
+    rows = []
+    for threads in (1, 4):
+        if threads > max(1, lbm_ref.max_threads()):
+            continue
+        lbm_ref.set_threads(threads)
+        o = lbm_ref.CavityOracleC(nx, ny, Re, semantics=semantics, collision=RT, dtype=np.dtype(dtype))
+        t = time.perf_counter(); o.step(1); one = time.perf_counter() - t      # (includes the first touch)
+        n = int(max(1, min(50, (budget_s - one) / max(one, 1e-6))))
+        t = time.perf_counter(); o.step(n); dt = time.perf_counter() - t
+        rows.append({"impl": "oracle/lbm_ref.c", "threads": threads, "lattice": [nx, ny], "case": f"{semantics} {RT} {dtype}",
+                     "MLUPS": round(nx * ny * n / dt / 1e6, 2), "steps": n})
+    lbm_ref.set_threads(1)
+    m = 1024
+    o = CavityOracle(m, m, 1000.0, semantics="mrt_py", collision="SRT", dtype=np.float64)
+    t = time.perf_counter(); o.step(1); one = time.perf_counter() - t
+    n = int(max(1, min(50, (budget_s - one) / max(one, 1e-6))))
+    t = time.perf_counter(); o.step(n); dt = time.perf_counter() - t
+    rows.append({"impl": "oracle/lbm_numpy.py", "threads": 1, "lattice": [m, m], "case": "mrt_py SRT float64 (what MRT.py runs)",
+                 "MLUPS": round(m * m * n / dt / 1e6, 2), "steps": n})
+    return rows
 
 
 def cpu_table():
@@ -133,6 +164,34 @@ def make_solver(config, scaling, world, rank, dev, kernel, arith, tuning=None):
         s.relax = relaxation(Re, OMEGA_HEIGHT[config], s.uLB, 1.2, 1.2)
         s.set_relaxation(0, **s.relax)
     return s, NY, rows
+
+
+PROTOCOL_KEYS = ("kernel", "steps_per_launch", "frame", "deep_halo", "stream", "vec", "layout", "units")
+
+
+def rank_plan(config, scaling, world, rank, kernel, arith, steps, tuning=None):
+    """Dry run (lbm_plan: host logic of the library, no GPU) of the launch plan rank `rank` would derive for this bench configuration:
+    the dict of CavitySolver.describe() + `units`, the launch units of `steps` steps from a fresh lattice.  The arguments go through
+    the same slab_of / partition_rows / min_rows path as make_solver."""
+    from latticeboltzmannsimulations_amd import launch_plan
+    from latticeboltzmannsimulations_amd.slab import partition_rows
+    nx, ny_gpu, Re, dtype, RT, sem, _ = CONFIGS[config]
+    NY, rows = slab_of(config, scaling, world, rank)
+    mr = min(n for _, n in partition_rows(NY, world)) if world > 1 else None
+    return launch_plan(nx, NY, Re, steps=steps, RT=RT, semantics=sem, dtype=np.dtype(dtype), rows=rows if world > 1 else None,
+                       kernel=kernel, arith=arith, min_rows=mr, tuning=tuning)
+
+
+def check_plans(config, scaling, world, kernel, arith, steps, tuning=None):
+    """Pre-flight of a multi-rank run: the plans of ALL ranks (each rank can compute every rank's: pure host logic) must agree on
+    everything that shapes the exchange protocol -- neighbours post matching send / receive sequences.  Returns (plans, None) or
+    (plans, "rank r: key a != b")."""
+    plans = [rank_plan(config, scaling, world, r, kernel, arith, steps, tuning) for r in range(world)]
+    for r in range(1, world):
+        for k in PROTOCOL_KEYS:
+            if plans[r].get(k) != plans[0].get(k):
+                return plans, f"rank {r}: {k} = {plans[r].get(k)!r}, rank 0: {plans[0].get(k)!r}"
+    return plans, None
 
 
 def unit_plan(solver, steps):
@@ -211,9 +270,22 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     nx, ny_gpu, Re, dtype, RT, sem, label = CONFIGS[a.config]
+    if world > 1:
+        # Pre-flight, before any rank creates its lattice: every rank derives the launch plan of EVERY rank (host logic only) and
+        # stops the job, naming the differing item, if two ranks would run different protocols.
+        plans, bad = check_plans(a.config, scaling, world, a.kernel, a.arith, a.warmup + a.steps)
+        if bad:
+            print(f"[rank {rank}] launch plans differ between ranks -- {bad}", file=sys.stderr, flush=True)
+            sys.exit(3)
     solver, NY, rows = make_solver(a.config, scaling, world, rank, dev, a.kernel, a.arith)
     if world > 1:
-        attach_rccl(solver, rank, world)
+        print(f"[rank {rank}] device {dev} rows {rows} plan: {solver.describe()}", file=sys.stderr, flush=True)
+        try:
+            attach_rccl(solver, rank, world)      # lbm_comm_init: communicator + the plan handshake with both neighbours
+        except RuntimeError as e:                 # LBM_ERR_STATE names the item a neighbour plans differently
+            print(f"[rank {rank}] lbm_comm_init failed: {e}", file=sys.stderr, flush=True)
+            sys.exit(4)
+        print(f"[rank {rank}] communicator up, plan handshake with the neighbours ok", file=sys.stderr, flush=True)
 
     def fence():
         solver.sync()
@@ -388,7 +460,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nx, NY, Re, dtype, RT, sem)
+            out["cpu_baseline"] = cpu_baseline(nx, NY, Re, dtype, RT, sem, table_s=3.0)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

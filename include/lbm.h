@@ -65,7 +65,9 @@ enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange af
        LBM_FLAG_NO_EDGE_FIRST = 4096,    /* streaming kernel between slabs: do not hold the bulk launch back behind the edge launch */
        LBM_FLAG_NO_EDGE_RESERVE = 8192,  /* ... and do not plan a one-round bulk launch on fewer CUs to leave some to the edge workgroups */
        LBM_FLAG_NO_XCD_BANDS = 16384,    /* streaming kernel: workgroup i takes segment i (default: every XCD a contiguous run of segments) */
-       LBM_FLAG_NO_TAIL_TILES = 32768 }; /* streaming contexts: units of 3 .. 5 steps through the streaming kernel too (default: the tile kernel) */
+       LBM_FLAG_NO_TAIL_TILES = 32768,   /* streaming contexts: units of 3 .. 5 steps through the streaming kernel too (default: the tile kernel) */
+       LBM_FLAG_NO_STREAM_WALLS = 65536 }; /* kernel STREAM, lone lattice, MRT_GPU semantics: the cells next to the walls as a frame of single-step
+                                            passes (r02) instead of inside the streaming kernel (k_stream_walls) */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
  * reference bakes them into the CUDA source by '%'-formatting (MRT_GPU.py:422,531,662) and
@@ -162,6 +164,12 @@ int lbm_next_unit(const lbm_ctx* c, int steps_left);
  * units (k_stream | k_stepS_deep | k_step2_deep | none), steps per launch, frame width, workgroups and strip rows of a launch, ...
  * Returns the length written (truncated to len - 1), negative on a bad argument. */
 int lbm_describe(const lbm_ctx* c, char* buf, size_t len);
+/* Dry run, NO device needed: the text lbm_describe() would give for lbm_create(p), followed by ` units=S1,S2,...` -- the launch units
+ * lbm_step(steps) would run from a freshly initialised lattice.  Derived from lbm_params alone, so a launcher can check, before any
+ * rank touches a GPU, that all ranks of a decomposition plan the same kernel / steps per launch / frame / deep halo and the same
+ * units (lbm_comm_init cross-checks the same items at run time).  ncu: compute units to plan for (0 = 256).  Invalid parameters:
+ * returns a negative status and writes `error: <reason>`.  (No counterpart in the reference, which runs one GPU.) */
+int lbm_plan(const lbm_params* p, int ncu, int steps, char* buf, size_t len);
 
 /* --- state out --------------------------------------------------------------------- */
 /* replaces: cuda.memcpy_dtoh(fin, ftemp_g); memcpy_dtoh(rho, rho_g); memcpy_dtoh(u, u_g)

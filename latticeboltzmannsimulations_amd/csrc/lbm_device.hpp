@@ -528,8 +528,13 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
 template <typename R, int COLL, int V, bool TURB>
 __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in)[Q], const Relax<R>& w0,
                                             typename VecT<R, V>::type (&outv)[Q],
-                                            typename VecT<R, V>::type& hq, typename VecT<R, V>::type& hr) {
+                                            typename VecT<R, V>::type& hq, typename VecT<R, V>::type& hr, bool wl = false, bool wr = false,
+                                            int kind = 0, typename VecT<R, V>::type* rho_out = nullptr) {
     // hq, hr: Smagorinsky history of the cells (in: previous step, out: this step); untouched unless TURB
+    // The streaming kernel with the walls inside (lbm_stream.hpp) passes wall cells, their wall rules already applied to in[]:
+    // wl / wr: the first / last cell is a side-wall cell (x = 0 / X - 1): u = 0 (MRT_GPU.py:396-399; as update_vec);
+    // kind 1: the V cells are lid cells -- rho = (f0+f1+f3) + 2 (f2+f5+f6), u = (uLB, 0) (MRT_GPU.py:400-405); kind 2: bottom-wall
+    // cells, u = 0; rho_out: receives the density (after the override) -- what the next step's lid rule needs
     if constexpr (sizeof(R) == 4 && V == 4) {
         // fp32: two cells per operation (packed math), same lane-wise IEEE operations as the scalar form below
 #pragma unroll
@@ -539,12 +544,21 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
             for (int k = 0; k < Q; ++k) g[k] = p == 0 ? in[k].xy : in[k].zw;
             f32x2 w_nu = (f32x2)(w0.w_nu);
             if (TURB) w_nu = smagorinsky_omega<f32x2, coll_is_fast(COLL)>(g, p == 0 ? hq.xy : hq.zw, p == 0 ? hr.xy : hr.zw, w0.w_nu);
-            const f32x2 rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+            f32x2 rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+            if (kind == 1) rho = ((g[0] + g[1]) + g[3]) + 2.f * ((g[2] + g[5]) + g[6]);
             if (!coll_is_mrt(COLL) || TURB) {
-                const f32x2 ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
-                const f32x2 uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
+                f32x2 ux, uy;
+                if (kind == 0) {
+                    ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
+                    uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
+                    if (wl && p == 0) { ux.x = 0.f; uy.x = 0.f; }
+                    if (wr && p == 1) { ux.y = 0.f; uy.y = 0.f; }
+                } else {
+                    ux = f32x2(kind == 1 ? w0.uLB : 0.f); uy = f32x2(0.f);
+                }
                 equ<f32x2>(rho, ux, uy, fe);
             }
+            if (rho_out) { if (p == 0) rho_out->xy = rho; else rho_out->zw = rho; }
             collide<f32x2, COLL>(g, rho, fe, w0, w_nu, out);
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
@@ -565,12 +579,20 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
             for (int k = 0; k < Q; ++k) g[k] = in[k][c];
             R w_nu = w0.w_nu;
             if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, hq[c], hr[c], w0.w_nu);
-            const R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+            R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+            if (kind == 1) rho = ((g[0] + g[1]) + g[3]) + (R)2. * ((g[2] + g[5]) + g[6]);
             if (!coll_is_mrt(COLL) || TURB) {
-                const R ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
-                const R uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
+                R ux, uy;
+                if (kind == 0) {
+                    ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
+                    uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
+                    if ((wl && c == 0) || (wr && c == V - 1)) { ux = (R)0; uy = (R)0; }
+                } else {
+                    ux = kind == 1 ? w0.uLB : (R)0; uy = (R)0;
+                }
                 equ<R>(rho, ux, uy, fe);
             }
+            if (rho_out) (*rho_out)[c] = rho;
             collide<R, COLL>(g, rho, fe, w0, w_nu, out);
 #pragma unroll
             for (int k = 0; k < Q; ++k) outv[k][c] = out[k];

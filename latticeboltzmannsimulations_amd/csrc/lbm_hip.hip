@@ -107,6 +107,7 @@ struct lbm_ctx {
     bool frame_beside = false;  // streaming kernel of a lone lattice: the frame passes as a kernel of their own on the second stream, BESIDE the
                                 // streaming workgroups (no LDS, ~70 VGPRs: fits next to them when the streaming kernel leaves registers)
     bool stream = false;        // ... by the strip-streaming kernel (lbm_stream.hpp: large lone lattices, up to 8 steps per launch)
+    bool stream_walls = false;  // ... with the walls inside (k_stream_walls: a lone lattice in MRT_GPU.py semantics; no frame) (A/B: LBM_FLAG_NO_STREAM_WALLS)
     int ncu = 256;              // compute units of the device (the streaming kernel runs one workgroup per CU)
     int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel), up to eight (streaming kernel)
     int tb_f = TB_F;            // frame width
@@ -359,9 +360,10 @@ bool has_neighbour(const lbm_ctx* c, int side);
 bool is_slab(const lbm_ctx* c);
 struct StreamPlan { int nstrips, nsegy, H; };
 StreamPlan plan_stream_on(const lbm_ctx* c, int S, int ncu, long long* cost_out) {
-    const int V = 16 / c->es, Rr = stream_rim(S, V), TXu = 64 * V - 2 * Rr, F = c->tb_f;
+    const int V = 16 / c->es, Rr = stream_rim(S, V), TXu = 64 * V - 2 * Rr, F = c->stream_walls ? 0 : c->tb_f;
     const int cols = c->geo.nx - 2 * F, rows = c->geo.ny - 2 * F;
-    StreamPlan best{(cols + TXu - 1) / TXu, 1, rows};
+    // (with the walls inside: strips over the whole width, no rim at a wall; segments over the whole height)
+    StreamPlan best{c->stream_walls ? stream_walls_strips(c->geo.nx, S, V) : (cols + TXu - 1) / TXu, 1, rows};
     long long best_cost = -1;
     for (int n = 1; n <= 256 && n * 8 <= std::max(rows, 8); ++n) {
         const int H = (rows + n - 1) / n, nseg = (rows + H - 1) / H;
@@ -401,6 +403,20 @@ StreamPlan plan_stream(const lbm_ctx* c, int S) {
 }
 
 int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_frame) {
+    if (c->stream_walls) {   // the whole lattice, walls included, in one launch of the streaming kernel: no frame at all
+        if (!with_frame) return fail(c, LBM_ERR_STATE, "internal: the streaming kernel with the walls inside takes the whole lattice");
+        dispatch(c->p, [&](auto v) {
+            using VT = decltype(v);
+            using R = typename VT::R;
+            if constexpr (VT::SEM == SEM_GPU) {
+                const StreamPlan pl = plan_stream(c, S);
+                hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s, (const R*)c->lat[from],
+                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, c->xcd_bands ? 1 : 0);
+            }
+        });
+        HIP_TRY(c, hipGetLastError());
+        return LBM_OK;
+    }
     const bool use_lds = frame_lds_fits(c, S, false, 0, ST_LDS_BYTES);
     if (with_frame && !use_lds) {
         const int rc = ensure_scratch(c, S - 1);
@@ -459,6 +475,13 @@ int warm_stream(lbm_ctx* c) {
     dispatch(c->p, [&](auto v) {
         using VT = decltype(v);
         using R = typename VT::R;
+        if constexpr (VT::SEM == SEM_GPU) {
+            if (c->stream_walls) {   // (H = 0: the one workgroup's segment is empty)
+                hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
+                                   c->geo, relax_of<R>(c->p), c->tb_steps, 1, 0, 0);
+                return;
+            }
+        }
         const int F = c->tb_f;
         const FramePtrs<R> fp = frame_ptrs<R>(c, 0, 1, 1);
         hipLaunchKernelGGL((k_stream<R, VT::COLL, VT::SEM, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
@@ -473,7 +496,7 @@ int launch_deep(lbm_ctx* c, int from, int to, hipStream_t s, int steps, bool wit
     // kernel costs nearly the same whatever its length (4096^2 fast: 311 us for four steps, 374 for eight), the tile kernel's four
     // steps take ~290 (strict ~300 against ~350): the driver's 20 timed steps, fast 1088 -> 1066 us, strict 1466 -> 1412
     // (profiles/r02_logs/tail_tiles.log)
-    const bool tail = c->stream && c->tail_tiles && with_frame && steps >= 3 && steps <= 5;
+    const bool tail = c->stream && c->tail_tiles && c->frame_fused && with_frame && steps >= 3 && steps <= 5;
     if (c->stream && !tail) return launch_stream(c, from, to, s, steps, with_frame);
     const int S_tile = steps >= 3 ? (steps == 4 || steps == 5 ? steps : 3) : 2;
     const bool tile_frame_lds = frame_lds_fits(c, S_tile, false, 0, TILE_FRAME_LDS_BYTES);
@@ -744,7 +767,7 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
 // column strips as separate launches on separate streams was measured and lost 8 %: profiles/r01_logs/perf31.log, perf35.log.)
 int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     const bool slab = is_slab(c);
-    if (!slab && c->frame_fused && S >= 3 && !(c->stream && c->frame_beside)) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
+    if (!slab && ((c->stream_walls && S >= 2) || (S >= 3 && c->frame_fused && !(c->stream && c->frame_beside)))) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
         HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // (frame launches of an earlier unit, if any)
         int rc = launch_deep(c, c->cur, c->cur ^ 1, c->s_compute, S, true);
         if (rc) return rc;
@@ -773,6 +796,26 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
         // edge launch -- when the bulk launch runs more than one round of workgroups (16384 x 2048 fp32 slab in loopback 319 -> 359
         // GLUPS, 8192 x 1024 fp64 133 -> 142); a one-round launch does not gain and a short one loses (4096 x 4096 355 -> 351,
         // 4096 x 1024 249 -> 205: profiles/r02_logs/slab_loopback7.log).
+        //
+        // Why the release (ev_go) and the early exchange cannot break an ordering -- unit n goes lat[a] -> lat[b]; E = exchange, G = edge
+        // launch, B = bulk launch; s_comm runs  E_n, wait(ev_int: B_{n-1}), [record ev_go], G_n, record ev_edges;  s_compute runs
+        // wait(ev_edges: G_{n-1}), [wait ev_go], B_n, record ev_int:
+        //   * E_n sends rows [0, S) / [ny - S, ny) of lat[a] and fills lat[a]'s ghost rows.  The rows it sends lie inside the F >= S edge
+        //     rows G_{n-1} wrote -- same stream, earlier -- unless the previous unit was no streaming unit: then edge_rows < S and
+        //     exchange_ready() makes s_comm wait for ev_int first.  Nothing else touches those rows or lat[a]'s ghost rows meanwhile:
+        //     B_{n-1}, which may still run, writes lat[a]'s rows [F, ny - F) only and reads lat[b].
+        //   * G_n reads lat[a] up to F + S - 1 rows from an interface plus the ghost rows: written by G_{n-1} and E_n (same stream,
+        //     earlier) and by B_{n-1} (the wait on ev_int sits between E_n and G_n).  It writes lat[b]'s edge rows, last read by
+        //     G_{n-1} / E_{n-1} (same stream, earlier) and by B_{n-1} (waited for).
+        //   * B_n reads lat[a]'s rows from F - (S - 1) on: B_{n-1}'s (same stream) and G_{n-1}'s (the wait on ev_edges, recorded after
+        //     G_{n-1}).  It writes lat[b]'s rows [F, ny - F): last read by B_{n-1} (same stream) and G_{n-1} (waited for).  The next
+        //     exchange E_{n+1}, which may run beside B_n, touches lat[b]'s edge and ghost rows only -- disjoint from B_n's.
+        //   * ev_go only ADDS an edge: B_n after everything s_comm had enqueued when it was recorded (E_n and the wait for B_{n-1}).  It is
+        //     recorded (host order) before s_compute is told to wait for it, and what it waits for -- ev_int of unit n - 1 -- was recorded
+        //     on s_compute before that wait: no cycle, no wait on an event not yet recorded.  Its price: B_n also waits for E_n, which it
+        //     does not need; E_n has had the whole of B_{n-1} to finish, so this costs only when a neighbour is that late -- and then G_n,
+        //     which B_{n+1} needs, waits for the same exchange anyway.
+        // (the events are re-recorded every unit: a wait refers to the last record before it in host order -- the one named above)
         const StreamPlan pl = plan_stream(c, S);
         if (c->edge_first && (long long)pl.nstrips * pl.nsegy > c->ncu) {
             HIP_TRY(c, hipEventRecord(c->ev_go, c->s_comm));
@@ -858,7 +901,7 @@ int prev_lattice(lbm_ctx* c, int* which) {
     const bool slab = is_slab(c);
     int rc;
     if (k >= 3 && c->tb_steps >= 3) {   // one multi-step launch of k steps (a slab: from the deep halo still in lat[from]'s ghost rows)
-        if (!slab && c->frame_fused) {
+        if (!slab && (c->frame_fused || c->stream_walls)) {
             rc = launch_deep(c, from, LAT_LAG, c->s_compute, k, true);
         } else {
             const bool lo = has_neighbour(c, LBM_SIDE_LOW), hi = has_neighbour(c, LBM_SIDE_HIGH);
@@ -1069,47 +1112,36 @@ int reduce_u_t(lbm_ctx* c) {
 // ------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------
-extern "C" {
-
-int lbm_abi_version(void) { return LBM_ABI_VERSION; }
-
-int lbm_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+// The checks of lbm_params that need no device ("" = fine).
+static std::string validate_params(const lbm_params* p) {
+    if (!p || p->struct_size != (int32_t)sizeof(lbm_params)) return std::string("lbm_params.struct_size mismatch");
+    if (p->nx < 4 || p->ny < 4) return std::string("nx, ny must be >= 4");
+    if (p->y0 < 0 || p->ny_local < 2 || p->y0 + p->ny_local > p->ny) return std::string("slab rows out of range (ny_local >= 2)");
+    if (p->ny_local > 65535) return std::string("ny_local > 65535 not supported");
+    if (p->dtype != LBM_F32 && p->dtype != LBM_F64) return std::string("dtype must be LBM_F32 or LBM_F64");
+    if (p->collision < LBM_SRT || p->collision > LBM_MRT) return std::string("collision must be SRT, TRT or MRT");
+    if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return std::string("bad semantics");
+    if (p->turb != 0 && p->turb != 1) return std::string("turb must be 0 or 1");
+    if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return std::string("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
+    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_STREAM) return std::string("bad kernel variant");
+    if (p->kernel == LBM_KERNEL_PUSH && (p->turb || p->batch > 1 || p->y0 != 0 || p->ny_local != p->ny))
+        return std::string("kernel = PUSH (the reference's two-launch scheme, for A/B) takes one whole lattice without the closure");
+    if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return std::string("bad layout");
+    if (p->batch < 0 || p->batch > 65535) return std::string("batch must be 0 .. 65535");
+    if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return std::string("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
+    if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return std::string("a batch of lattices cannot be slab-decomposed");
+    if (p->ny_local_min < 0 || p->ny_local_min > p->ny_local) return std::string("ny_local_min must be 0 or the smallest ny_local of all ranks (<= ny_local)");
+    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > ST_MAX_S)) return std::string("tb_steps must be 0 (default) or 2 .. " + std::to_string(ST_MAX_S));
+    if (p->frame_seg != 0 && p->frame_seg < 8) return std::string("frame_seg must be 0 (default) or >= 8");
+    if ((p->flags & LBM_FLAG_NT_ON) && (p->flags & LBM_FLAG_NT_OFF)) return std::string("LBM_FLAG_NT_ON and LBM_FLAG_NT_OFF exclude each other");
+    return std::string();
 }
 
-lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
-    auto bail = [&](const std::string& m) -> lbm_ctx* {
-        if (err && errlen) { std::snprintf(err, errlen, "%s", m.c_str()); }
-        return nullptr;
-    };
-    if (!p || p->struct_size != (int32_t)sizeof(lbm_params)) return bail("lbm_params.struct_size mismatch");
-    if (p->nx < 4 || p->ny < 4) return bail("nx, ny must be >= 4");
-    if (p->y0 < 0 || p->ny_local < 2 || p->y0 + p->ny_local > p->ny) return bail("slab rows out of range (ny_local >= 2)");
-    if (p->ny_local > 65535) return bail("ny_local > 65535 not supported");
-    if (p->dtype != LBM_F32 && p->dtype != LBM_F64) return bail("dtype must be LBM_F32 or LBM_F64");
-    if (p->collision < LBM_SRT || p->collision > LBM_MRT) return bail("collision must be SRT, TRT or MRT");
-    if (p->semantics != LBM_SEM_MRT_PY && p->semantics != LBM_SEM_MRT_GPU) return bail("bad semantics");
-    if (p->turb != 0 && p->turb != 1) return bail("turb must be 0 or 1");
-    if (p->turb == 1 && p->semantics != LBM_SEM_MRT_GPU) return bail("turb = 1 (Smagorinsky, MRT_GPU.py:368-387) exists only with MRT_GPU semantics");
-    if (p->kernel < LBM_KERNEL_AUTO || p->kernel > LBM_KERNEL_STREAM) return bail("bad kernel variant");
-    if (p->kernel == LBM_KERNEL_PUSH && (p->turb || p->batch > 1 || p->y0 != 0 || p->ny_local != p->ny))
-        return bail("kernel = PUSH (the reference's two-launch scheme, for A/B) takes one whole lattice without the closure");
-    if (p->layout < LBM_LAYOUT_AUTO || p->layout > LBM_LAYOUT_ROWS) return bail("bad layout");
-    if (p->batch < 0 || p->batch > 65535) return bail("batch must be 0 .. 65535");
-    if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return bail("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
-    if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return bail("a batch of lattices cannot be slab-decomposed");
-    if (p->ny_local_min < 0 || p->ny_local_min > p->ny_local) return bail("ny_local_min must be 0 or the smallest ny_local of all ranks (<= ny_local)");
-    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > ST_MAX_S)) return bail("tb_steps must be 0 (default) or 2 .. " + std::to_string(ST_MAX_S));
-    if (p->frame_seg != 0 && p->frame_seg < 8) return bail("frame_seg must be 0 (default) or >= 8");
-    if ((p->flags & LBM_FLAG_NT_ON) && (p->flags & LBM_FLAG_NT_OFF)) return bail("LBM_FLAG_NT_ON and LBM_FLAG_NT_OFF exclude each other");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0) return bail(std::string("no HIP device: ") + hipGetErrorString(e));
-    if (p->device < 0 || p->device >= ndev) return bail("device ordinal out of range");
-    if ((e = hipSetDevice(p->device)) != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e));
-
+// Context with geometry and LAUNCH PLAN filled in from lbm_params alone -- no HIP call unless `device` (then the register counts of
+// two kernels are read for the frame_beside rule).  lbm_create continues from here; lbm_plan (a dry run: what would every rank of a
+// decomposition plan?) stops here.
+static lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
+    auto bail = [&](const std::string& m) -> lbm_ctx* { err_out = m; return nullptr; };
     lbm_ctx* c = new (std::nothrow) lbm_ctx();
     if (!c) return bail("out of host memory");
     c->p = *p;
@@ -1215,7 +1247,10 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
             // in fp32 the frame waves slow the streaming waves by more than the 43 us they save, 367 -> 338
             // (profiles/r02_logs/stream_ab18.log)
             c->tail_tiles = !slab && c->batch == 1 && c->es == 4 && p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_TAIL_TILES);
-            if (slab) c->frame_beside = false;   // (a slab's frame is its edge launch, multi_step)
+            // The walls inside the streaming kernel (k_stream_walls, lbm_stream.hpp): a lone lattice in MRT_GPU.py semantics needs no
+            // frame -- side-wall cells in line, the lid and the bottom row as blocks of the pipeline.
+            c->stream_walls = !slab && c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_STREAM_WALLS);
+            if (slab || c->stream_walls) c->frame_beside = false;   // (a slab's frame is its edge launch, multi_step; no frame at all with the walls inside)
             else if (p->flags & LBM_FLAG_FRAME_BESIDE_ON) c->frame_beside = true;
             else if (!(p->flags & LBM_FLAG_FRAME_BESIDE_OFF) && c->batch == 1 && c->es == 8) {
                 int rs = 1 << 20, rf = 1 << 20;
@@ -1223,6 +1258,7 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
                     using VT = decltype(v);
                     using R = typename VT::R;
                     hipFuncAttributes at;
+                    if (!device) return;
                     if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_stream<R, VT::COLL, VT::SEM, VT::TURB>)) == hipSuccess) rs = at.numRegs;
                     if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_frame_beside<R, VT::COLL, VT::SEM, VT::TURB>)) == hipSuccess) rf = at.numRegs;
                 });
@@ -1264,6 +1300,38 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         c->use_nt = (p->flags & LBM_FLAG_NT_ON) ? true : (p->flags & LBM_FLAG_NT_OFF) ? false : (bytes > ((size_t)192 << 20));
         c->lazy_lag = !(p->flags & LBM_FLAG_EAGER_LAG);
     }
+    return c;
+}
+
+extern "C" {
+
+int lbm_abi_version(void) { return LBM_ABI_VERSION; }
+
+int lbm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
+    auto bail = [&](const std::string& m) -> lbm_ctx* {
+        if (err && errlen) { std::snprintf(err, errlen, "%s", m.c_str()); }
+        return nullptr;
+    };
+    {
+        const std::string bad = validate_params(p);
+        if (!bad.empty()) return bail(bad);
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return bail(std::string("no HIP device: ") + hipGetErrorString(e));
+    if (p->device < 0 || p->device >= ndev) return bail("device ordinal out of range");
+    if ((e = hipSetDevice(p->device)) != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+    std::string plan_err;
+    lbm_ctx* c = plan_ctx(p, true, plan_err);
+    if (!c) return bail(plan_err);
+    const size_t bytes = c->lat_bytes;
     auto cleanup = [&](const std::string& m) -> lbm_ctx* { lbm_destroy(c); return bail(m); };
     {
         hipDeviceProp_t prop;
@@ -1403,15 +1471,16 @@ int lbm_next_unit(const lbm_ctx* c, int steps_left) {
 
 int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
     if (!c || !buf || len == 0) return LBM_ERR_INVALID;
-    const char* kern = !c->use_tb ? "none" : c->stream ? "k_stream" : c->tb_steps == 2 ? "k_step2_deep" : "k_stepS_deep";
+    const char* kern = !c->use_tb ? "none" : c->stream_walls ? "k_stream_walls" : c->stream ? "k_stream" : c->tb_steps == 2 ? "k_step2_deep" : "k_stepS_deep";
     const int S = c->use_tb ? c->tb_steps : 1;
     long long wgs = 0, wave_updates = 0;   // per launch of S steps: workgroups of the bulk kernel; (wave, level) updates they perform
     const int V = 16 / c->es;
     if (c->stream) {
         const StreamPlan pl = plan_stream(c, S);
         wgs = (long long)pl.nstrips * pl.nsegy;
-        const long long rows = c->geo.ny - 2 * c->tb_f;
-        wave_updates = (long long)pl.nstrips * (rows + (long long)pl.nsegy * 2 * (S - 1)) * S;
+        const long long rows = c->geo.ny - (c->stream_walls ? 0 : 2 * c->tb_f);
+        // (with the walls inside the first / last segment has no lead rows beyond the wall)
+        wave_updates = (long long)pl.nstrips * (rows + ((long long)pl.nsegy * 2 - (c->stream_walls ? 2 : 0)) * (S - 1)) * S;
     } else if (c->use_tb && S >= 3) {
         const int F = c->tb_f, RV = (S - 1 + V - 1) / V, TX = (16 - 2 * RV) * V, TY = 32 - 2 * (S - 1);
         const long long ntx = (c->geo.nx - 2 * F + TX - 1) / TX, nty = (c->geo.ny - 2 * F + TY - 1) / TY;
@@ -1425,10 +1494,45 @@ int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
     const int n = std::snprintf(buf, len, "kernel=%s steps_per_launch=%d frame=%d stream=%d vec=%d nt=%d deep_halo=%d frame_fused=%d lazy_lag=%d "
                                 "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d frame_beside=%d frame_seg=%d "
                                 "lattices=%d lattice_bytes=%lld",
-                                kern, S, c->use_tb ? c->tb_f : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
+                                kern, S, c->use_tb ? (c->stream_walls ? 0 : c->tb_f) : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
                                 c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->geo.row != c->geo.pitch ? "rows" : "planes", wgs, wave_updates, V,
                                 is_slab(c) ? 1 : 0, c->frame_beside ? 1 : 0, c->frame_seg, nlat, (long long)c->lat_bytes);
     return n < 0 ? LBM_ERR_INVALID : (n >= (int)len ? (int)len - 1 : n);
+}
+
+// Dry run of the launch plan: what lbm_create(p) would plan and which launch units lbm_step(steps) would then run from a fresh
+// lattice -- derived from lbm_params alone, NO device call (works without a GPU).  Every rank of a slab decomposition must get the
+// same kernel / steps_per_launch / frame / deep_halo and the same units (they post matching send / receive sequences; lbm_comm_init
+// cross-checks at run time): this lets a launcher -- and the CPU tests -- check a decomposition before any rank touches a GPU.
+// ncu: compute units to plan for (0 = 256, an MI355X).  frame_beside depends on the kernels' register counts and is reported 0
+// unless forced by a flag (lone lattices only: no effect on the protocol).
+int lbm_plan(const lbm_params* p, int ncu, int steps, char* buf, size_t len) {
+    if (!buf || len == 0) return LBM_ERR_INVALID;
+    const std::string bad = validate_params(p);
+    std::string perr;
+    lbm_ctx* c = bad.empty() ? plan_ctx(p, false, perr) : nullptr;
+    if (!c) {
+        std::snprintf(buf, len, "error: %s", (bad.empty() ? perr : bad).c_str());
+        return LBM_ERR_INVALID;
+    }
+    c->ncu = ncu > 0 ? ncu : 256;
+    int n = lbm_describe(c, buf, len);
+    if (n >= 0) {
+        std::string u = " units=";
+        int left = steps < 0 ? 0 : steps;
+        bool raw = true;
+        while (left > 0) {
+            const int S = unit_steps(c, left, raw);
+            if (S < 1) break;
+            u += std::to_string(S);
+            left -= S;
+            if (left > 0) u += ",";
+            raw = false;
+        }
+        if ((size_t)n + u.size() < len) { std::memcpy(buf + n, u.c_str(), u.size() + 1); n += (int)u.size(); }
+    }
+    delete c;
+    return n;
 }
 
 int lbm_sync(lbm_ctx* c) {

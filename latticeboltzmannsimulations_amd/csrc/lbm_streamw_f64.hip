@@ -1,0 +1,5 @@
+// lbm_streamw_f64.hip -- explicit instantiations of the streaming kernel with the walls inside, double (k_stream_walls, lbm_stream.hpp)
+#define LBM_STREAMW_EXTERN
+#define LBM_STREAM_ONLY_F64
+#define LBM_STREAM_SKIP
+#include "lbm_stream.hpp"

@@ -138,10 +138,20 @@ def locate_vortices(u, uLB):
     return tuple(int(v) for v in loc1), tuple(int(v) for v in loc2)
 
 
-def profile_errors(u, Re, uLB):
+# The three transcription slips of GhiaData.csv versus the paper (header of this module): (column, Re, row).  The table is kept as the
+# reference ships it; a comparison that wants the physics leaves these points out (`mask_typos`).
+TYPOS = (("uy", 400, 2), ("ux", 3200, 9), ("ux", 10000, 8))
+# One more entry no solution can meet: Uy(x = 0.9063) at Re = 400 reads -0.23827 in the CSV exactly as in the paper's table, between
+# -0.22847 and -0.44993; every converged run here (oracle and HIP, 128^2 .. 256^2) gives -0.34 .. -0.35 there and is within 0.03 of all
+# its neighbours -- a misprint of the paper itself (commonly read as -0.33827).  Masked together with the transcription slips.
+PAPER_MISPRINTS = (("uy", 400, 5),)
+
+
+def profile_errors(u, Re, uLB, mask_typos=False):
     """Geometrically consistent comparison with Ghia (not in the reference): the lattice node
     (x, y) sits at (x/(X-1), 1 - y/(Y-1)); linear interpolation of the LBM centrelines at the
-    Ghia sample positions.  Returns (max |dUx|, max |dUy|) in lid-velocity units."""
+    Ghia sample positions.  Returns (max |dUx|, max |dUy|) in lid-velocity units; mask_typos leaves
+    out the table entries listed in TYPOS and PAPER_MISPRINTS."""
     _, X, Y = u.shape
     Yg, Uxg, Xg, Uyg = ghia_profiles(Re)
     ux, uy = centrelines(u.astype(np.float64), uLB)
@@ -149,4 +159,42 @@ def profile_errors(u, Re, uLB):
     ux_i = np.interp(Yg, height[::-1], ux[::-1])
     # cy = +1 populations move towards y - 1, i.e. towards the lid: u[1] > 0 is Ghia's v > 0
     uy_i = np.interp(Xg, np.arange(X) / (X - 1.0), uy)
-    return float(np.max(np.abs(ux_i - Uxg))), float(np.max(np.abs(uy_i - Uyg)))
+    kx, ky = np.ones(len(Yg), bool), np.ones(len(Xg), bool)
+    if mask_typos:
+        for col, re_, row in TYPOS + PAPER_MISPRINTS:
+            if re_ == int(round(float(Re))):
+                (kx if col == "ux" else ky)[row] = False
+    return float(np.max(np.abs(ux_i - Uxg)[kx])), float(np.max(np.abs(uy_i - Uyg)[ky]))
+
+
+def vortex_position(loc, X, Y):
+    """A located lattice node in the coordinates the reference plots it in beside Ghia's vortex table (MRT.py:551-553,
+    MRT_GPU.py:803-805): (i / xsize, (ysize_max - j) / ysize) -- x from the left wall, y from the BOTTOM wall, as in the table."""
+    return loc[0] / float(X), (Y - 1 - loc[1]) / float(Y)
+
+
+def nearest_vortex_error(loc, Re, X, Y):
+    """Distance from a located node (locate_vortices returns the two smallest minima of |u|^2 -- WHICH vortices they are depends on the
+    flow: at Re >= 400 the first is the bottom-left corner eddy, not the primary vortex) to the nearest entry of Ghia's vortex table
+    for this Re, in the reference's plot coordinates: (distance, index of that table row: 0 Primary, 1 Top, 2 BL1, 3 BR1, ...)."""
+    px, py = vortex_position(loc, X, Y)
+    j = _col(Re)
+    xv, yv = VORTEX_GHIA[0:7, j], VORTEX_GHIA[7:14, j]
+    d = np.where((xv != 0) | (yv != 0), np.hypot(xv - px, yv - py), np.inf)
+    i = int(np.argmin(d))
+    return float(d[i]), i
+
+
+def primary_vortex_error(u, Re, uLB):
+    """(dx, dy) between the minimum of |u|^2 inside the central box 0.25 .. 0.75 of the cavity -- the primary vortex; not in the
+    reference, whose two-minima search does not tell the vortices apart -- and the `Primary` row of Ghia's vortex table (VORTEX_GHIA
+    rows 0 / 7; MRT.py:105,113-116), in the reference's plot coordinates."""
+    _, X, Y = u.shape
+    usq = u[0].astype(np.float64) ** 2 + u[1].astype(np.float64) ** 2
+    box = np.full_like(usq, np.inf)
+    x0, x1, y0, y1 = X // 4, X - X // 4, Y // 4, Y - Y // 4
+    box[x0:x1, y0:y1] = usq[x0:x1, y0:y1]
+    loc = np.unravel_index(np.argmin(box), box.shape)
+    px, py = vortex_position(loc, X, Y)
+    j = _col(Re)
+    return px - VORTEX_GHIA[0, j], py - VORTEX_GHIA[7, j]

@@ -35,7 +35,7 @@ def _tuning(t):
     off = {"deep_halo": L.LBM_FLAG_NO_DEEP_HALO, "frame_fused": L.LBM_FLAG_FRAME_UNFUSED, "frame_lds": L.LBM_FLAG_NO_FRAME_LDS,
            "comm_priority": L.LBM_FLAG_COMM_PRIORITY_OFF, "frame_wide": L.LBM_FLAG_FRAME_NARROW, "edge_first": L.LBM_FLAG_NO_EDGE_FIRST,
            "edge_reserve": L.LBM_FLAG_NO_EDGE_RESERVE, "xcd_bands": L.LBM_FLAG_NO_XCD_BANDS,
-           "tail_tiles": L.LBM_FLAG_NO_TAIL_TILES}
+           "tail_tiles": L.LBM_FLAG_NO_TAIL_TILES, "stream_walls": L.LBM_FLAG_NO_STREAM_WALLS}
     on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG}
     for k, bit in off.items():
         if not t.pop(k, True):
@@ -100,20 +100,9 @@ class CavitySolver:
         self._omega_eps, self._omega_q = omega_eps, omega_q
         self.relax = relaxation(self.Re, self.ny, self.uLB, omega_eps, omega_q)
         self.y0, self.ny_local = (0, self.ny) if rows is None else (int(rows[0]), int(rows[1]))
-        p = L.lbm_params()
-        p.struct_size = ctypes.sizeof(L.lbm_params)
-        p.nx, p.ny, p.y0, p.ny_local = self.nx, self.ny, self.y0, self.ny_local
-        p.dtype, p.collision, p.semantics = _DT[self.dtype], _COLL[RT], _SEM[semantics]
-        p.kernel, p.turb, p.device = _KERNEL[kernel], int(turb), int(device)
-        p.layout = _LAYOUT[layout]
-        p.batch = self.batch
-        p.arith = _ARITH[arith]
-        p.ny_local_min = 0 if min_rows is None else int(min_rows)
-        p.tb_steps, p.frame_seg, p.flags = _tuning(tuning)
         self.turb = int(turb)
-        p.uLB = self.uLB
-        p.omega, p.omegam = self.relax["omega"], self.relax["omegam"]
-        p.omega_e, p.omega_eps, p.omega_q = self.relax["omega_e"], self.relax["omega_eps"], self.relax["omega_q"]
+        p = _params(self.nx, self.ny, self.y0, self.ny_local, self.dtype, RT, semantics, kernel, turb, device, layout, self.batch, arith,
+                    min_rows, tuning, self.uLB, self.relax)
         err = ctypes.create_string_buffer(512)
         h = self.lib.lbm_create(ctypes.byref(p), err, len(err))
         if not h:
@@ -340,6 +329,47 @@ class CavityBatch(CavitySolver):
         raise NotImplementedError("checkpoint the lattices of a batch one by one through get_fields / set_state")
 
     load_checkpoint = save_checkpoint
+
+
+def _params(nx, ny, y0, ny_local, dtype, RT, semantics, kernel, turb, device, layout, batch, arith, min_rows, tuning, uLB, relax):
+    """lbm_params of include/lbm.h from the Python-level arguments."""
+    p = L.lbm_params()
+    p.struct_size = ctypes.sizeof(L.lbm_params)
+    p.nx, p.ny, p.y0, p.ny_local = int(nx), int(ny), int(y0), int(ny_local)
+    p.dtype, p.collision, p.semantics = _DT[np.dtype(dtype)], _COLL[RT], _SEM[semantics]
+    p.kernel, p.turb, p.device = _KERNEL[kernel], int(turb), int(device)
+    p.layout = _LAYOUT[layout]
+    p.batch = int(batch)
+    p.arith = _ARITH[arith]
+    p.ny_local_min = 0 if min_rows is None else int(min_rows)
+    p.tb_steps, p.frame_seg, p.flags = _tuning(tuning)
+    p.uLB = float(uLB)
+    p.omega, p.omegam = relax["omega"], relax["omegam"]
+    p.omega_e, p.omega_eps, p.omega_q = relax["omega_e"], relax["omega_eps"], relax["omega_q"]
+    return p
+
+
+def launch_plan(xsize, ysize, Re, steps=0, ncu=0, RT="MRT", uLB=0.08, semantics="mrt_gpu", dtype=np.float32, turb=0, rows=None,
+                kernel="auto", layout="auto", batch=1, arith="strict", min_rows=None, tuning=None):
+    """Dry run (lbm_plan, NO GPU needed): the launch plan lbm_create would derive for these arguments -- the dict of
+    CavitySolver.describe() -- plus `units`, the launch units step(steps) would run from a fresh lattice.  All ranks of a slab
+    decomposition must agree on kernel / steps_per_launch / frame / deep_halo and on the units: a launcher (bench.py --gpus N) and
+    the CPU tests check that before any rank touches a device."""
+    ny = int(ysize)
+    y0, nyl = (0, ny) if rows is None else (int(rows[0]), int(rows[1]))
+    relax = relaxation(float(Re), ny, float(uLB), 1.0 if semantics == "mrt_py" else 1.2, 1.2)
+    p = _params(xsize, ny, y0, nyl, dtype, RT, semantics, kernel, turb, 0, layout, batch, arith, min_rows, tuning, uLB, relax)
+    buf = ctypes.create_string_buffer(1024)
+    rc = L.lib().lbm_plan(ctypes.byref(p), int(ncu), int(steps), buf, len(buf))
+    text = buf.value.decode()
+    if rc < 0:
+        raise RuntimeError("lbm_plan: " + text)
+    out = {}
+    for kv in text.split():
+        k, v = kv.split("=", 1)
+        out[k] = int(v) if v.lstrip("-").isdigit() else v
+    out["units"] = [int(x) for x in str(out.get("units", "")).split(",") if x != ""]
+    return out
 
 
 def _npz(path):

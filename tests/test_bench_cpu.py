@@ -62,3 +62,44 @@ def test_slab_plan_of_the_multi_gpu_bench():
     NY, (y0, n) = bench.slab_of("c5", "weak", 8, 7)
     assert (NY, y0, n) == (16384, 14336, 2048)                   # BASELINE configs[4]: 16384 x 16384 over 8 GPUs
     assert bench.OMEGA_HEIGHT["c5"] == 16384
+
+
+def test_cpu_baseline_table_is_bounded_and_complete():
+    """cpu_baseline.table of the driver line: the C restatement at 1 and 4 threads (functions.pyx:69) on the same
+    lattice and the NumPy restatement of MRT.py at 1 thread, each bounded."""
+    import time
+    t = time.time()
+    rows = bench.cpu_baseline_table(256, 256, 1000.0, "float32", "MRT", "mrt_gpu", budget_s=0.2)
+    assert time.time() - t < 30
+    assert [r["threads"] for r in rows if r["impl"] == "oracle/lbm_ref.c"] in ([1, 4], [1])
+    assert rows[-1]["impl"] == "oracle/lbm_numpy.py" and rows[-1]["threads"] == 1 and all(r["MLUPS"] > 0 for r in rows)
+
+
+def test_every_rank_of_the_multi_gpu_bench_plans_the_same_protocol():
+    """bench.py --gpus N for N = 2, 4, 8 x {c3, c4, c5}, driven through bench.py's own slab_of / partition_rows /
+    min_rows argument path, with the LIBRARY's plan logic (lbm_plan: lbm_create's launch plan + lbm_next_unit's units, no device):
+    every rank must derive the same kernel, steps per launch, frame width, deep halo and the same sequence of launch units -- they post
+    matching send / receive sequences (lbm_comm_init cross-checks the same items at run time).  Also: first / middle / last rank get
+    the slab flag, N = 1 does not; an uneven cut (neighbours on opposite sides of a size threshold) agrees through
+    min_rows, and WITHOUT min_rows the check catches the disagreement."""
+    from latticeboltzmannsimulations_amd import launch_plan
+    from latticeboltzmannsimulations_amd.slab import partition_rows
+    for cfg in ("c3", "c4", "c5"):
+        scaling = bench.DEFAULT_SCALING[cfg]
+        for world in (2, 4, 8):
+            for arith in ("fast", "strict"):
+                plans, bad = bench.check_plans(cfg, scaling, world, "auto", arith, 25)
+                assert bad is None, (cfg, world, arith, bad)
+                assert [q["slab"] for q in plans] == [1] * world and sum(plans[0]["units"]) == 25 and plans[0]["units"][0] == 1
+                assert plans[0]["deep_halo"] == 1 and plans[0]["steps_per_launch"] >= 3, (cfg, world, plans[0])
+                # the figures the protocol uses are those of the smallest slab
+                NY = bench.slab_of(cfg, scaling, world, 0)[0]
+                assert min(n for _, n in partition_rows(NY, world)) >= 2 * plans[0]["frame"]
+    one = bench.rank_plan("c3", "strong", 1, 0, "auto", "fast", 20)
+    assert one["slab"] == 0 and one["kernel"] == "k_stream_walls" and one["units"] == [1, 8, 8, 3]
+    # 768 x 1535 rows cut in two: 768 and 767 rows sit on opposite sides of the tile kernel's size threshold
+    parts = partition_rows(1535, 2)
+    with_min = [launch_plan(768, 1535, 1000.0, steps=12, rows=r, min_rows=min(n for _, n in parts)) for r in parts]
+    assert all(with_min[0][k] == with_min[1][k] for k in bench.PROTOCOL_KEYS)
+    without = [launch_plan(768, 1535, 1000.0, steps=12, rows=r) for r in parts]
+    assert any(without[0][k] != without[1][k] for k in bench.PROTOCOL_KEYS), "the example no longer straddles a threshold: pick another"

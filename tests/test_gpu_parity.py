@@ -193,17 +193,24 @@ def test_one_step_lag_after_every_kind_of_last_unit(dtype, coll, turb):
 
 @pytest.mark.parametrize("sem,coll,turb", [("mrt_gpu", "MRT", 0), ("mrt_gpu", "SRT", 1), ("mrt_gpu", "TRT", 0), ("mrt_py", "SRT", 0), ("mrt_gpu", "MRT", 1)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_streaming_kernel_is_bit_identical_to_oracle(sem, coll, turb, dtype):
+@pytest.mark.parametrize("walls", [True, False])
+def test_streaming_kernel_is_bit_identical_to_oracle(sem, coll, turb, dtype, walls):
     """kernel='stream' (lbm_stream.hpp): up to 8 time steps per launch streamed down column strips -- rows in registers,
     neighbour rows through LDS, x neighbours by DPP.  Sizes with one and several strips (partial last strip), one and several
     row segments, every steps-per-launch setting 2 .. 8 (frame widths 4 / 8 / 12), call lengths that leave every remainder
     (tail units of 3 .. 7 steps, single steps), fields read after units of every length (lagged lattice recomputed by the same
-    kernel)."""
-    for nx, ny, tbs in ((320, 192, 8), (1028, 80, 0), (132, 600, 5), (516, 300, 7), (260, 131, 2), (64, 64, 8), (772, 257, 6), (304, 99, 3), (288, 160, 4)):
+    kernel).  walls: the cells next to the walls inside the streaming kernel (k_stream_walls, the default for a lone lattice in
+    MRT_GPU.py semantics since r03: side walls in line, lid / bottom row as blocks of the pipeline, corner kept slots carried) or as
+    the r02 frame of single-step passes (what slabs and MRT.py semantics still run)."""
+    if walls and sem == "mrt_py":
+        pytest.skip("the walls inside the streaming kernel: MRT_GPU.py semantics only (MRT.py lattices keep the frame: the other leg)")
+    for nx, ny, tbs in ((320, 192, 8), (1028, 80, 0), (132, 600, 5), (516, 300, 7), (260, 131, 2), (64, 64, 8), (772, 257, 6), (304, 99, 3), (288, 160, 4),
+                        (256, 70, 8), (252, 75, 8), (496, 64, 8), (500, 67, 7), (64, 200, 8)):
         o = CavityOracleC(nx, ny, 1000.0, semantics=sem, collision=coll, dtype=dtype, turb=turb)
         # (the wall frame inside the launch or as a kernel of its own beside the streaming workgroups: alternate, whatever the default)
         with CavitySolver(nx, ny, 1000.0, RT=coll, semantics=sem, dtype=dtype, turb=turb, kernel="stream",
-                          tuning=dict(tb_steps=tbs, frame_beside=bool((nx // 4) % 2))) as s:
+                          tuning=dict(tb_steps=tbs, frame_beside=bool((nx // 4) % 2), stream_walls=walls)) as s:
+            assert (s.describe()["kernel"] == "k_stream_walls") == walls, s.describe()
             for n in (1, 8, 19, 3, 7, 12):
                 o.step(n); s.step(n)
                 same(s, o, f"stream {nx}x{ny} tb_steps={tbs} {sem} {coll} turb={turb} after {o.nsteps} steps")
@@ -258,7 +265,7 @@ def test_seeded_random_configurations_of_the_streaming_kernel():
         tbs = int(rng.integers(3, 9))
         Re = [100.0, 1000.0, 5000.0][rng.integers(3)]
         chunks = [int(v) for v in rng.integers(1, 23, size=3)]
-        tune = dict(tb_steps=tbs, tail_tiles=bool(rng.integers(2)), xcd_bands=bool(rng.integers(2)))
+        tune = dict(tb_steps=tbs, tail_tiles=bool(rng.integers(2)), xcd_bands=bool(rng.integers(2)), stream_walls=bool(rng_fast.integers(2)))
         arith = "fast" if (sem == "mrt_gpu" and rng_fast.random() < 0.34) else "strict"
         what = f"case {case}: {nx}x{ny} {sem} {coll} {np.dtype(dtype).name} turb={turb} S={tbs} slabs={nslabs} {chunks} {tune} {arith}"
         o = CavityOracleC(nx, ny, Re, semantics=sem, collision=coll, dtype=dtype, turb=turb)
@@ -615,6 +622,37 @@ def test_converged_cavity_matches_ghia(Re, n, RT, dtype, tol, arith):
     assert abs(fin.sum() - n * n) / (n * n) < 2e-2
 
 
+@pytest.mark.parametrize("Re,n,dtype,arith,kernel,cap,tol", [
+    (400, 256, np.float64, "strict", "auto", 600_000, 0.04), (400, 256, np.float32, "fast", "stream", 400_000, 0.04),
+    (3200, 256, np.float32, "strict", "stream", 800_000, 0.05), (3200, 256, np.float64, "fast", "auto", 1_200_000, 0.05),
+    (5000, 384, np.float32, "fast", "auto", 2_400_000, 0.04), (5000, 256, np.float64, "strict", "auto", 1_800_000, 0.055)])
+def test_converged_cavity_matches_the_other_ghia_columns_and_the_vortex_table(Re, n, dtype, arith, kernel, cap, tol):
+    """the only fixtures the reference holds for this path are GhiaData.csv's centreline columns and its vortex
+    table (MRT.py:104-116).  Re = 400, 3200 (configs[3]) and 5000 (configs[4]), MRT, run to the reference's convergence criterion
+    (MRT_GPU.py:883-889, on the device mean; fp32 means do not settle to 1e-8, those runs stop at `cap`, past the fp64 runs' count):
+    (a) centrelines at the geometrically correct positions against the Ghia columns, the table's known bad entries masked (ghia.TYPOS,
+    ghia.PAPER_MISPRINTS) -- measured r03: Re 400 0.014 / 0.031, Re 3200 0.038 / 0.041 (256^2), Re 5000 0.028 / 0.024 (384^2), 0.042 /
+    0.044 (256^2); (b) the primary vortex centre against VORTEX_GHIA rows 0 / 7 within two Ghia grid spacings (2 / 128); (c) the two
+    minima of |u|^2 the reference's own search returns (MRT_GPU.py:764-778) each sit on a vortex of the table (within 3 / 128)."""
+    with CavitySolver(n, n, float(Re), RT="MRT", dtype=dtype, arith=arith, kernel=kernel) as s:
+        prev, quiet = None, 0
+        while s.steps_done < cap and quiet <= 5:
+            s.step(3000)
+            m = s.mean_u()
+            quiet = quiet + 1 if (prev is not None and abs(m - prev) / 0.08 < 1e-8) else 0
+            prev = m
+        u, rho = s.get_fields(out_dtype=np.float64)
+    assert np.isfinite(u).all()
+    ex, ey = ghia.profile_errors(u, Re, 0.08, mask_typos=True)
+    dx, dy = ghia.primary_vortex_error(u, Re, 0.08)
+    near = [ghia.nearest_vortex_error(l, Re, n, n) for l in ghia.locate_vortices(u, 0.08)]
+    print(f"\nRe={Re} {n}^2 {np.dtype(dtype).name} {arith} {kernel}: steps {s.steps_done}, max|dUx| {ex:.4f}, max|dUy| {ey:.4f}, primary vortex "
+          f"({dx:+.4f}, {dy:+.4f}), reference's two minima -> nearest table vortex (distance, row) {near}")
+    assert ex < tol and ey < tol, (ex, ey)
+    assert abs(dx) <= 2 / 128 + 1e-9 and abs(dy) <= 2 / 128 + 1e-9, (dx, dy)
+    assert all(d <= 3 / 128 for d, _ in near), near
+
+
 @pytest.mark.parametrize("sem,coll", [("mrt_gpu", "MRT"), ("mrt_gpu", "TRT"), ("mrt_py", "SRT")])
 def test_minimum_sizes_and_empty_calls(sem, coll):
     """Edge cases: the smallest lattices the library accepts (4 x 4: every cell is a wall cell or next to one), two-row
@@ -880,7 +918,7 @@ def test_streaming_kernel_fast_arithmetic_every_instantiation(coll, turb, dtype)
     with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="generic", arith="fast") as g, \
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast", tuning=dict(tb_steps=8)) as s8, \
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast",
-                         tuning=dict(tb_steps=3, frame_beside=True, tail_tiles=False)) as s3:
+                         tuning=dict(tb_steps=3, frame_beside=True, tail_tiles=False, stream_walls=False)) as s3:
         for n in calls:
             o.step(n); g.step(n); s8.step(n); s3.step(n)
             # (the first unit of a freshly initialised lattice is a single step; from then on the streaming plan applies)

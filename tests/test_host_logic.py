@@ -113,6 +113,37 @@ def test_locate_vortices_finds_two_minima_away_from_the_walls():
     assert ghia.locate_vortices(u2, 0.08)[1] == c2
 
 
+def test_vortex_table_helpers_and_masked_profile_errors():
+    """r03: the comparisons with GhiaData.csv's vortex table (MRT.py:105,113-116) and the masks for its known bad centreline entries.
+    vortex_position is the reference's plot mapping (MRT.py:551-553); a node put exactly on a table vortex has distance ~0 to it; the
+    primary-vortex search looks in the central box only; mask_typos removes exactly the listed entries."""
+    X = Y = 256
+    j = ghia.RE_COLUMNS.index(1000)
+    # the node whose plot coordinates are the table's BL1 vortex at Re = 1000 (0.0859, 0.0781)
+    loc = (int(round(ghia.VORTEX_GHIA[2, j] * X)), Y - 1 - int(round(ghia.VORTEX_GHIA[9, j] * Y)))
+    d, row = ghia.nearest_vortex_error(loc, 1000, X, Y)
+    assert row == 2 and d < 1.0 / X
+    assert ghia.vortex_position((0, Y - 1), X, Y) == (0.0, 0.0)
+    xx, yy = np.meshgrid(np.arange(X), np.arange(Y), indexing="ij")
+    prim = (int(round(ghia.VORTEX_GHIA[0, j] * X)), Y - 1 - int(round(ghia.VORTEX_GHIA[7, j] * Y)))
+    speed = np.minimum(np.hypot(xx - prim[0], yy - prim[1]) + 0.5, np.hypot(xx - loc[0], yy - loc[1])) * 1e-3   # the corner eddy is the deeper minimum
+    u = np.stack([speed, np.zeros_like(speed)])
+    assert ghia.locate_vortices(u, 0.08)[0] == loc                     # the reference's search finds the corner eddy first ...
+    dx, dy = ghia.primary_vortex_error(u, 1000, 0.08)                  # ... the central-box search the primary vortex
+    assert abs(dx) < 1.0 / X and abs(dy) < 1.0 / Y
+    # masks: a field that reproduces the Re = 400 table exactly except where the table is wrong
+    n = 257
+    Yg, Uxg, Xg, Uyg = ghia.ghia_profiles(400)
+    good = Uyg.copy(); good[2] = -0.15663; good[5] = -0.33827
+    u = np.zeros((2, n, n))
+    u[1, :, n // 2] = np.interp(np.arange(n) / (n - 1.0), Xg[::-1], good[::-1]) * 0.08
+    u[0, n // 2, :] = np.interp(1.0 - np.arange(n) / (n - 1.0), Yg[::-1], Uxg[::-1]) * 0.08
+    ex, ey = ghia.profile_errors(u, 400, 0.08)
+    mx, my = ghia.profile_errors(u, 400, 0.08, mask_typos=True)
+    assert ey > 0.3 and my < 0.02 and ex < 0.02 and mx == ex
+    assert ("uy", 400, 2) in ghia.TYPOS and ("uy", 400, 5) in ghia.PAPER_MISPRINTS
+
+
 def test_partition_rows():
     assert partition_rows(4096, 1) == [(0, 4096)]
     assert partition_rows(8192, 8) == [(i * 1024, 1024) for i in range(8)]
