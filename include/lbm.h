@@ -66,8 +66,10 @@ enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange af
        LBM_FLAG_NO_EDGE_RESERVE = 8192,  /* ... and do not plan a one-round bulk launch on fewer CUs to leave some to the edge workgroups */
        LBM_FLAG_NO_XCD_BANDS = 16384,    /* streaming kernel: workgroup i takes segment i (default: every XCD a contiguous run of segments) */
        LBM_FLAG_NO_TAIL_TILES = 32768,   /* streaming contexts: units of 3 .. 5 steps through the streaming kernel too (default: the tile kernel) */
-       LBM_FLAG_NO_STREAM_WALLS = 65536 }; /* kernel STREAM, lone lattice, MRT_GPU semantics: the cells next to the walls as a frame of single-step
-                                            passes (r02) instead of inside the streaming kernel (k_stream_walls) */
+       LBM_FLAG_STREAM_WALLS = 65536,    /* kernel STREAM, lone lattice, MRT_GPU semantics (r03 experiments, slower than the default -- DESIGN 2.4;
+                                            kept for A/B): the cells next to the walls inside the streaming kernel (k_stream_walls) instead of
+                                            a frame of single-step passes ... */
+       LBM_FLAG_STREAM_PAIRS = 131072 }; /* ... and two rows per wave, twelve waves, at most 10 steps per launch (k_stream_pairs; implies the former) */
 
 /* The knobs of the reference script (MRT_GPU.py:38-93) as run-time parameters.  The
  * reference bakes them into the CUDA source by '%'-formatting (MRT_GPU.py:422,531,662) and
@@ -99,7 +101,7 @@ typedef struct lbm_params {
     int32_t ny_local_min; /* slabs: the smallest ny_local of ALL ranks (0: = ny_local).  The launch plan (steps per launch, frame
                             width, deep halo) is derived from it, so that every rank of a decomposition runs the same exchange
                             protocol whatever its own share of the rows; lbm_comm_init() cross-checks the plan with both neighbours. */
-    int32_t tb_steps;    /* 0: measured default.  2 .. 5 (STREAM: 2 .. 8): time steps per launch of the multi-step path (A/B, tests) */
+    int32_t tb_steps;    /* 0: measured default.  2 .. 5 (STREAM: 2 .. 8; a lone MRT_GPU lattice, two rows per wave: 2 .. 10): time steps per launch of the multi-step path (A/B, tests) */
     int32_t frame_seg;   /* 0: default by lattice size.  >= 8: cells of the wall frame per workgroup of the fused frame passes */
     int32_t flags;       /* LBM_FLAG_* bits, 0 = defaults */
     double uLB;          /* lid velocity, MRT_GPU.py:57 */

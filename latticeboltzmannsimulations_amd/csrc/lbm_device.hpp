@@ -529,12 +529,12 @@ template <typename R, int COLL, int V, bool TURB>
 __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in)[Q], const Relax<R>& w0,
                                             typename VecT<R, V>::type (&outv)[Q],
                                             typename VecT<R, V>::type& hq, typename VecT<R, V>::type& hr, bool wl = false, bool wr = false,
-                                            int kind = 0, typename VecT<R, V>::type* rho_out = nullptr) {
+                                            int kind = 0) {
     // hq, hr: Smagorinsky history of the cells (in: previous step, out: this step); untouched unless TURB
     // The streaming kernel with the walls inside (lbm_stream.hpp) passes wall cells, their wall rules already applied to in[]:
     // wl / wr: the first / last cell is a side-wall cell (x = 0 / X - 1): u = 0 (MRT_GPU.py:396-399; as update_vec);
     // kind 1: the V cells are lid cells -- rho = (f0+f1+f3) + 2 (f2+f5+f6), u = (uLB, 0) (MRT_GPU.py:400-405); kind 2: bottom-wall
-    // cells, u = 0; rho_out: receives the density (after the override) -- what the next step's lid rule needs
+    // cells, u = 0
     if constexpr (sizeof(R) == 4 && V == 4) {
         // fp32: two cells per operation (packed math), same lane-wise IEEE operations as the scalar form below
 #pragma unroll
@@ -558,7 +558,6 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
                 }
                 equ<f32x2>(rho, ux, uy, fe);
             }
-            if (rho_out) { if (p == 0) rho_out->xy = rho; else rho_out->zw = rho; }
             collide<f32x2, COLL>(g, rho, fe, w0, w_nu, out);
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
@@ -570,6 +569,9 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
                 if (p == 0) { hq.xy = q2; hr.xy = rho; }
                 else { hq.zw = q2; hr.zw = rho; }
             }
+#ifdef LBM_SEQ_HALVES
+            if (p == 0) __builtin_amdgcn_sched_barrier(0);   // (experiment: the two halves one after the other -- fewer live temporaries)
+#endif
         }
     } else {
 #pragma unroll
@@ -592,7 +594,6 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
                 }
                 equ<R>(rho, ux, uy, fe);
             }
-            if (rho_out) (*rho_out)[c] = rho;
             collide<R, COLL>(g, rho, fe, w0, w_nu, out);
 #pragma unroll
             for (int k = 0; k < Q; ++k) outv[k][c] = out[k];

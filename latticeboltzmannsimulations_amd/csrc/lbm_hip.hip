@@ -107,7 +107,8 @@ struct lbm_ctx {
     bool frame_beside = false;  // streaming kernel of a lone lattice: the frame passes as a kernel of their own on the second stream, BESIDE the
                                 // streaming workgroups (no LDS, ~70 VGPRs: fits next to them when the streaming kernel leaves registers)
     bool stream = false;        // ... by the strip-streaming kernel (lbm_stream.hpp: large lone lattices, up to 8 steps per launch)
-    bool stream_walls = false;  // ... with the walls inside (k_stream_walls: a lone lattice in MRT_GPU.py semantics; no frame) (A/B: LBM_FLAG_NO_STREAM_WALLS)
+    bool stream_walls = false;  // ... with the walls inside (k_stream_walls: a lone lattice in MRT_GPU.py semantics; no frame) (opt-in: LBM_FLAG_STREAM_WALLS)
+    bool stream_pairs = false;  // ... and two rows per wave (k_stream_pairs: twelve waves, up to 10 steps per launch) (opt-in: LBM_FLAG_STREAM_PAIRS)
     int ncu = 256;              // compute units of the device (the streaming kernel runs one workgroup per CU)
     int tb_steps = 2;           // ... or three to five (in-place LDS tile kernel), up to eight (streaming kernel)
     int tb_f = TB_F;            // frame width
@@ -359,6 +360,8 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
 bool has_neighbour(const lbm_ctx* c, int side);
 bool is_slab(const lbm_ctx* c);
 struct StreamPlan { int nstrips, nsegy, H; };
+// waves per workgroup of k_stream_pairs for S steps per launch: two idle pair-slots to load the next pair in
+int pairs_waves(int S) { return std::min(SP_MAX_WAVES, S + 2); }
 StreamPlan plan_stream_on(const lbm_ctx* c, int S, int ncu, long long* cost_out) {
     const int V = 16 / c->es, Rr = stream_rim(S, V), TXu = 64 * V - 2 * Rr, F = c->stream_walls ? 0 : c->tb_f;
     const int cols = c->geo.nx - 2 * F, rows = c->geo.ny - 2 * F;
@@ -368,7 +371,11 @@ StreamPlan plan_stream_on(const lbm_ctx* c, int S, int ncu, long long* cost_out)
     for (int n = 1; n <= 256 && n * 8 <= std::max(rows, 8); ++n) {
         const int H = (rows + n - 1) / n, nseg = (rows + H - 1) / H;
         const long long segs = (long long)best.nstrips * nseg, rounds = (segs + ncu - 1) / ncu;
-        const long long iters = (H + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
+        long long iters = (H + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
+        if (c->stream_pairs) {   // W waves, a pair of rows each: 2 W iterations per W pairs
+            const long long Wv = pairs_waves(S), np = (H + 2 * (S - 1) + 1) / 2;
+            iters = 2 * Wv * ((np + Wv - 1) / Wv) + 2 * Wv;
+        }
         const long long cost = rounds * iters;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best.nsegy = nseg; best.H = H; }
     }
@@ -410,8 +417,12 @@ int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_
             using R = typename VT::R;
             if constexpr (VT::SEM == SEM_GPU) {
                 const StreamPlan pl = plan_stream(c, S);
-                hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s, (const R*)c->lat[from],
-                                   (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, c->xcd_bands ? 1 : 0);
+                if (c->stream_pairs)
+                    hipLaunchKernelGGL((k_stream_pairs<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * pl.nsegy), dim3(64 * pairs_waves(S)), 0, s,
+                                       (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, c->xcd_bands ? 1 : 0);
+                else
+                    hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s, (const R*)c->lat[from],
+                                       (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, c->xcd_bands ? 1 : 0);
             }
         });
         HIP_TRY(c, hipGetLastError());
@@ -477,8 +488,12 @@ int warm_stream(lbm_ctx* c) {
         using R = typename VT::R;
         if constexpr (VT::SEM == SEM_GPU) {
             if (c->stream_walls) {   // (H = 0: the one workgroup's segment is empty)
-                hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
-                                   c->geo, relax_of<R>(c->p), c->tb_steps, 1, 0, 0);
+                if (c->stream_pairs)
+                    hipLaunchKernelGGL((k_stream_pairs<R, VT::COLL, VT::TURB>), dim3(1), dim3(64 * pairs_waves(c->tb_steps)), 0, c->s_compute, (const R*)c->lat[0],
+                                       (R*)c->lat[1], c->geo, relax_of<R>(c->p), c->tb_steps, 1, 0, 0);
+                else
+                    hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
+                                       c->geo, relax_of<R>(c->p), c->tb_steps, 1, 0, 0);
                 return;
             }
         }
@@ -1131,7 +1146,7 @@ static std::string validate_params(const lbm_params* p) {
     if (p->arith != LBM_ARITH_STRICT && p->arith != LBM_ARITH_FAST) return std::string("arith must be LBM_ARITH_STRICT or LBM_ARITH_FAST");
     if (p->batch > 1 && (p->y0 != 0 || p->ny_local != p->ny)) return std::string("a batch of lattices cannot be slab-decomposed");
     if (p->ny_local_min < 0 || p->ny_local_min > p->ny_local) return std::string("ny_local_min must be 0 or the smallest ny_local of all ranks (<= ny_local)");
-    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > ST_MAX_S)) return std::string("tb_steps must be 0 (default) or 2 .. " + std::to_string(ST_MAX_S));
+    if (p->tb_steps != 0 && (p->tb_steps < 2 || p->tb_steps > SP_MAX_S)) return std::string("tb_steps must be 0 (default) or 2 .. " + std::to_string(SP_MAX_S));
     if (p->frame_seg != 0 && p->frame_seg < 8) return std::string("frame_seg must be 0 (default) or >= 8");
     if ((p->flags & LBM_FLAG_NT_ON) && (p->flags & LBM_FLAG_NT_OFF)) return std::string("LBM_FLAG_NT_ON and LBM_FLAG_NT_OFF exclude each other");
     return std::string();
@@ -1249,7 +1264,16 @@ static lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out)
             c->tail_tiles = !slab && c->batch == 1 && c->es == 4 && p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_TAIL_TILES);
             // The walls inside the streaming kernel (k_stream_walls, lbm_stream.hpp): a lone lattice in MRT_GPU.py semantics needs no
             // frame -- side-wall cells in line, the lid and the bottom row as blocks of the pipeline.
-            c->stream_walls = !slab && c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_STREAM_WALLS);
+            c->stream_walls = !slab && c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU && (p->flags & (LBM_FLAG_STREAM_WALLS | LBM_FLAG_STREAM_PAIRS));
+            // ... and two rows per wave (k_stream_pairs): twelve waves that all work in every iteration, 10 steps per launch by default (up
+            // to SP_MAX_S), a launch that costs in proportion to its steps -- so no tile-kernel tails
+            c->stream_pairs = c->stream_walls && (p->flags & LBM_FLAG_STREAM_PAIRS);
+            if (c->stream_pairs) {
+                c->tb_steps = p->tb_steps ? p->tb_steps : 10;
+                c->tail_tiles = false;
+            } else if (c->tb_steps > ST_MAX_S) {
+                return (delete c, bail("tb_steps " + std::to_string(ST_MAX_S + 1) + " .. " + std::to_string(SP_MAX_S) + " need the streaming kernel with two rows per wave (a lone lattice, MRT_GPU semantics)"));
+            }
             if (slab || c->stream_walls) c->frame_beside = false;   // (a slab's frame is its edge launch, multi_step; no frame at all with the walls inside)
             else if (p->flags & LBM_FLAG_FRAME_BESIDE_ON) c->frame_beside = true;
             else if (!(p->flags & LBM_FLAG_FRAME_BESIDE_OFF) && c->batch == 1 && c->es == 8) {
@@ -1265,7 +1289,7 @@ static lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out)
                 c->frame_beside = (rs + 7) / 8 * 8 * 4 + (rf + 7) / 8 * 8 <= 512;
             }
         } else {
-            if (want > 5) return (delete c, bail("tb_steps 6 .. " + std::to_string(ST_MAX_S) + " need kernel = STREAM"));
+            if (want > 5) return (delete c, bail("tb_steps 6 .. " + std::to_string(SP_MAX_S) + " need kernel = STREAM (above " + std::to_string(ST_MAX_S) + ": a lone lattice in MRT_GPU semantics)"));
             c->tb_steps = want == 2 ? 2 : ((want == 4 || want == 5) && deep_ok ? want : 3);
             c->tb_f = c->tb_steps >= 4 ? 2 * TB_F : TB_F;   // F >= S + 1 and a multiple of the vector width
         }
@@ -1471,7 +1495,7 @@ int lbm_next_unit(const lbm_ctx* c, int steps_left) {
 
 int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
     if (!c || !buf || len == 0) return LBM_ERR_INVALID;
-    const char* kern = !c->use_tb ? "none" : c->stream_walls ? "k_stream_walls" : c->stream ? "k_stream" : c->tb_steps == 2 ? "k_step2_deep" : "k_stepS_deep";
+    const char* kern = !c->use_tb ? "none" : c->stream_pairs ? "k_stream_pairs" : c->stream_walls ? "k_stream_walls" : c->stream ? "k_stream" : c->tb_steps == 2 ? "k_step2_deep" : "k_stepS_deep";
     const int S = c->use_tb ? c->tb_steps : 1;
     long long wgs = 0, wave_updates = 0;   // per launch of S steps: workgroups of the bulk kernel; (wave, level) updates they perform
     const int V = 16 / c->es;

@@ -2,4 +2,5 @@
 #define LBM_STREAMW_EXTERN
 #define LBM_STREAM_ONLY_F64
 #define LBM_STREAM_SKIP
+#define LBM_STREAMP_SKIP
 #include "lbm_stream.hpp"

@@ -35,8 +35,9 @@ def _tuning(t):
     off = {"deep_halo": L.LBM_FLAG_NO_DEEP_HALO, "frame_fused": L.LBM_FLAG_FRAME_UNFUSED, "frame_lds": L.LBM_FLAG_NO_FRAME_LDS,
            "comm_priority": L.LBM_FLAG_COMM_PRIORITY_OFF, "frame_wide": L.LBM_FLAG_FRAME_NARROW, "edge_first": L.LBM_FLAG_NO_EDGE_FIRST,
            "edge_reserve": L.LBM_FLAG_NO_EDGE_RESERVE, "xcd_bands": L.LBM_FLAG_NO_XCD_BANDS,
-           "tail_tiles": L.LBM_FLAG_NO_TAIL_TILES, "stream_walls": L.LBM_FLAG_NO_STREAM_WALLS}
-    on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG}
+           "tail_tiles": L.LBM_FLAG_NO_TAIL_TILES}
+    on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG,
+          "stream_walls": L.LBM_FLAG_STREAM_WALLS, "stream_pairs": L.LBM_FLAG_STREAM_PAIRS}
     for k, bit in off.items():
         if not t.pop(k, True):
             flags |= bit

@@ -158,7 +158,9 @@ def test_documented_limits_follow_the_source_constants():
     max_s = waves // 2
     hdr = open(os.path.join(ROOT, "include", "lbm.h")).read()
     assert f"1 <= nrows <= {ghy - 1}" in hdr and f"carries {ghy} ghost rows" in hdr
-    assert f"(at most {max_s};" in hdr and f"STREAM: 2 .. {max_s}" in hdr
+    max_p = int(re.search(r"constexpr int SP_MAX_WAVES = (\d+);", st).group(1)) - 2
+    assert re.search(r"constexpr int SP_MAX_S = SP_MAX_WAVES - 2;", st)
+    assert f"(at most {max_s};" in hdr and f"STREAM: 2 .. {max_s}; a lone MRT_GPU lattice, two rows per wave: 2 .. {max_p}" in hdr
     src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith(".hip"))
-    assert "std::to_string(GHY - 1)" in src and "std::to_string(ST_MAX_S)" in src
+    assert "std::to_string(GHY - 1)" in src and "std::to_string(ST_MAX_S)" in src and "std::to_string(SP_MAX_S)" in src
     assert not re.search(r"<= nrows <= \d", src), "a literal row limit in an error message"

@@ -193,28 +193,33 @@ def test_one_step_lag_after_every_kind_of_last_unit(dtype, coll, turb):
 
 @pytest.mark.parametrize("sem,coll,turb", [("mrt_gpu", "MRT", 0), ("mrt_gpu", "SRT", 1), ("mrt_gpu", "TRT", 0), ("mrt_py", "SRT", 0), ("mrt_gpu", "MRT", 1)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("walls", [True, False])
-def test_streaming_kernel_is_bit_identical_to_oracle(sem, coll, turb, dtype, walls):
+@pytest.mark.parametrize("mode", ["pairs", "walls", "frame"])
+def test_streaming_kernel_is_bit_identical_to_oracle(sem, coll, turb, dtype, mode):
     """kernel='stream' (lbm_stream.hpp): up to 8 time steps per launch streamed down column strips -- rows in registers,
     neighbour rows through LDS, x neighbours by DPP.  Sizes with one and several strips (partial last strip), one and several
     row segments, every steps-per-launch setting 2 .. 8 (frame widths 4 / 8 / 12), call lengths that leave every remainder
     (tail units of 3 .. 7 steps, single steps), fields read after units of every length (lagged lattice recomputed by the same
-    kernel).  walls: the cells next to the walls inside the streaming kernel (k_stream_walls, the default for a lone lattice in
-    MRT_GPU.py semantics since r03: side walls in line, lid / bottom row as blocks of the pipeline, corner kept slots carried) or as
-    the r02 frame of single-step passes (what slabs and MRT.py semantics still run)."""
-    if walls and sem == "mrt_py":
+    kernel).  mode: "frame" = the default (k_stream: the cells next to the walls as a frame of single-step passes); the two r03
+    experiments kept for A/B, both bit-identical too: "walls" = the walls inside the streaming kernel (k_stream_walls: side walls on the
+    lane shifts, lid / bottom row as rows of the pipeline, corner kept slots carried; a lone lattice in MRT_GPU.py semantics) and "pairs" =
+    that with two rows per wave, twelve waves, up to 10 steps per launch (k_stream_pairs)."""
+    if mode != "frame" and sem == "mrt_py":
         pytest.skip("the walls inside the streaming kernel: MRT_GPU.py semantics only (MRT.py lattices keep the frame: the other leg)")
-    for nx, ny, tbs in ((320, 192, 8), (1028, 80, 0), (132, 600, 5), (516, 300, 7), (260, 131, 2), (64, 64, 8), (772, 257, 6), (304, 99, 3), (288, 160, 4),
-                        (256, 70, 8), (252, 75, 8), (496, 64, 8), (500, 67, 7), (64, 200, 8)):
+    walls = mode != "frame"
+    sizes = ((320, 192, 8), (1028, 80, 0), (132, 600, 5), (516, 300, 7), (260, 131, 2), (64, 64, 8), (772, 257, 6), (304, 99, 3), (288, 160, 4),
+             (256, 70, 8), (252, 75, 8), (496, 64, 8), (500, 67, 7), (64, 200, 8))
+    if mode == "pairs":      # ... and the step counts only this kernel takes; odd row counts (a pair without a B row), one-pair segments
+        sizes += ((320, 193, 10), (516, 301, 10), (1028, 81, 9), (260, 64, 10), (128, 65, 9))
+    for nx, ny, tbs in sizes:
         o = CavityOracleC(nx, ny, 1000.0, semantics=sem, collision=coll, dtype=dtype, turb=turb)
         # (the wall frame inside the launch or as a kernel of its own beside the streaming workgroups: alternate, whatever the default)
         with CavitySolver(nx, ny, 1000.0, RT=coll, semantics=sem, dtype=dtype, turb=turb, kernel="stream",
-                          tuning=dict(tb_steps=tbs, frame_beside=bool((nx // 4) % 2), stream_walls=walls)) as s:
-            assert (s.describe()["kernel"] == "k_stream_walls") == walls, s.describe()
+                          tuning=dict(tb_steps=tbs, frame_beside=bool((nx // 4) % 2), stream_walls=mode == "walls", stream_pairs=mode == "pairs")) as s:
+            assert s.describe()["kernel"] == {"pairs": "k_stream_pairs", "walls": "k_stream_walls", "frame": "k_stream"}[mode], s.describe()
             for n in (1, 8, 19, 3, 7, 12):
                 o.step(n); s.step(n)
                 same(s, o, f"stream {nx}x{ny} tb_steps={tbs} {sem} {coll} turb={turb} after {o.nsteps} steps")
-            assert s.next_unit(100) == (tbs or 8) or min(nx, ny) < 80
+            assert s.next_unit(100) == (tbs or (10 if mode == "pairs" else 8)) or min(nx, ny) < 80
 
 
 def test_seeded_random_configurations_against_oracle():
@@ -265,7 +270,7 @@ def test_seeded_random_configurations_of_the_streaming_kernel():
         tbs = int(rng.integers(3, 9))
         Re = [100.0, 1000.0, 5000.0][rng.integers(3)]
         chunks = [int(v) for v in rng.integers(1, 23, size=3)]
-        tune = dict(tb_steps=tbs, tail_tiles=bool(rng.integers(2)), xcd_bands=bool(rng.integers(2)), stream_walls=bool(rng_fast.integers(2)))
+        tune = dict(tb_steps=tbs, tail_tiles=bool(rng.integers(2)), xcd_bands=bool(rng.integers(2)), stream_walls=bool(rng_fast.integers(2)), stream_pairs=bool(rng_fast.integers(2)))
         arith = "fast" if (sem == "mrt_gpu" and rng_fast.random() < 0.34) else "strict"
         what = f"case {case}: {nx}x{ny} {sem} {coll} {np.dtype(dtype).name} turb={turb} S={tbs} slabs={nslabs} {chunks} {tune} {arith}"
         o = CavityOracleC(nx, ny, Re, semantics=sem, collision=coll, dtype=dtype, turb=turb)
@@ -916,21 +921,24 @@ def test_streaming_kernel_fast_arithmetic_every_instantiation(coll, turb, dtype)
     calls = (1, 8, 19, 3, 7, 12, 50)
     o = CavityOracleC(nx, ny, 5000.0, semantics="mrt_gpu", collision=coll, dtype=dtype, turb=turb)
     with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="generic", arith="fast") as g, \
-            CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast", tuning=dict(tb_steps=8)) as s8, \
+            CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast", tuning=dict(tb_steps=8, stream_pairs=True)) as s8, \
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast",
-                         tuning=dict(tb_steps=3, frame_beside=True, tail_tiles=False, stream_walls=False)) as s3:
+                         tuning=dict(tb_steps=3, frame_beside=True, tail_tiles=False)) as s3, \
+            CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast",
+                         tuning=dict(tb_steps=5, stream_walls=True)) as sw:
         for n in calls:
-            o.step(n); g.step(n); s8.step(n); s3.step(n)
+            o.step(n); g.step(n); s8.step(n); s3.step(n); sw.step(n)
             # (the first unit of a freshly initialised lattice is a single step; from then on the streaming plan applies)
-            assert s8.next_unit(100) == 8 and s3.next_unit(100) == 3
+            assert s8.next_unit(100) == 8 and s3.next_unit(100) == 3 and sw.next_unit(100) == 5
+            assert (s8.describe()["kernel"], sw.describe()["kernel"], s3.describe()["kernel"]) == ("k_stream_pairs", "k_stream_walls", "k_stream")
             ref = g.get_fields(want_fin=True)
-            for name, s in (("S=8", s8), ("S=3", s3)):
+            for name, s in (("S=8 pairs", s8), ("S=3 frame", s3), ("S=5 walls", sw)):
                 got = s.get_fields(want_fin=True)
                 assert all(np.array_equal(x, y) for x, y in zip(ref, got)), (name, coll, turb, np.dtype(dtype).name, o.nsteps)
             assert np.abs(ref[2] - o.fin).max() / np.abs(o.fin).max() < tol_f
             assert np.abs(ref[0] - o.u).max() / 0.08 < tol_u and np.abs(ref[1] - o.rho).max() < tol_u
         if turb:
-            assert np.array_equal(g.get_tau(), s8.get_tau()) and np.array_equal(g.get_tau(), s3.get_tau())
+            assert np.array_equal(g.get_tau(), s8.get_tau()) and np.array_equal(g.get_tau(), s3.get_tau()) and np.array_equal(g.get_tau(), sw.get_tau())
 
 
 def test_fast_arithmetic_config_c1_centrelines():
@@ -1177,10 +1185,14 @@ def test_unit_api_messages_quote_the_accepted_ranges():
             s.step_unit(9)
         with pytest.raises(RuntimeError, match=r"3 \.\. 8"):
             s.step_unit(2)
-    with pytest.raises(RuntimeError, match=r"2 \.\. 8"):
-        CavitySolver(320, 200, 100.0, tuning=dict(tb_steps=9))
-    with pytest.raises(RuntimeError, match=r"6 \.\. 8 need kernel = STREAM"):
+    with pytest.raises(RuntimeError, match=r"2 \.\. 10"):
+        CavitySolver(320, 200, 100.0, tuning=dict(tb_steps=12))
+    with pytest.raises(RuntimeError, match=r"6 \.\. 10 need kernel = STREAM"):
         CavitySolver(320, 200, 100.0, kernel="tb", tuning=dict(tb_steps=6))
+    with pytest.raises(RuntimeError, match=r"9 \.\. 10 need the streaming kernel with two rows per wave"):
+        CavitySolver(320, 400, 100.0, kernel="stream", rows=(0, 200), tuning=dict(tb_steps=9, stream_pairs=True))        # (a slab: 8 at most)
+    with CavitySolver(320, 200, 100.0, kernel="stream", tuning=dict(tb_steps=10, stream_pairs=True)) as s:
+        assert s.describe()["kernel"] == "k_stream_pairs" and s.describe()["steps_per_launch"] == 10
 
 
 def test_slab_without_a_communicator_is_refused():
