@@ -140,16 +140,42 @@ rccl_api& rccl() {
     static rccl_api a;
     if (a.ok || !a.err.empty()) return a;
     void* h = nullptr;
-    // a copy that is already mapped first, under either name (PyTorch bundles "librccl.so", ROCm installs "librccl.so.1"): two RCCLs
-    // in one process abort in their exit handlers
+    // r02's exit abort ("double free or corruption (!prev)", rc 134, when a process created a communicator here and imported torch
+    // afterwards) -- cause, from two backtraces (profiles/r03_logs/rc134_gdb.log, rc134_gdb2.log): the abort is in exit(), in the
+    // destructor of the namespace-scope  std::map<amd::smi::DevInfoTypes, const char*>  that librocm_smi64 AND libamd_smi both define
+    // (the same sources, one default-visibility symbol).  This function used to dlopen RCCL with RTLD_GLOBAL, which puts RCCL's
+    // dependency librocm_smi64 into the process's GLOBAL symbol scope; a library with the same symbol that is mapped later --
+    // the PyTorch wheel's librocm_smi64 (soname .7, beside /opt/rocm's .1), or /opt/rocm's libamd_smi.so, which `import torch` pulls
+    // in -- then binds its own static initialiser and its own atexit destructor to the FIRST definition: one object, constructed twice,
+    // destroyed twice.  With torch imported first nothing was global and each library kept its own copy.  Fix, in the library (a C
+    // caller is covered too): RCCL is opened RTLD_LOCAL -- its entry points are taken with dlsym from the handle anyway -- so nothing
+    // of its dependency chain can be interposed on.  On top of that, ONE ROCm stack per process: (1) a copy of RCCL that is already
+    // mapped, under either name (PyTorch bundles "librccl.so", ROCm installs "librccl.so.1"); (2) else the RCCL that sits next to the
+    // HIP runtime THIS process runs on (the loader says where hipGetDeviceCount lives: a Python process with PyTorch installed runs on
+    // the wheel's bundled libamdhip64, _lib.py preloads it; a C caller on /opt/rocm's) -- its $ORIGIN rpath keeps its whole
+    // dependency chain in that installation; (3) else by name.
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : {"librccl.so", "librccl.so.1"}) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (h) break;
+    }
+    if (!h) {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* n : {"librccl.so", "librccl.so.1"}) {
+                    h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL);
+                    if (h) break;
+                }
+            }
+        }
     }
     for (const char* n : names) {
         if (h) break;
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!h) { a.err = std::string("dlopen(librccl): ") + dlerror(); return a; }
 #define RCCL_SYM(field, sym)                                                        \

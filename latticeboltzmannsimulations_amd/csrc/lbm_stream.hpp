@@ -508,7 +508,6 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
     const int y_first = max(ya - (S - 1), 0), y_end = min(yb + (S - 1), geo.ny);
     const int nb = y_end - y_first, npairs = (nb + 1) >> 1;       // (an odd row count: the last pair's B row is a dummy that nobody reads)
     const int x0 = xs + lane * V;
-    const bool lane_in = x0 < geo.nx;
     const bool lane_out = x0 >= own_lo && x0 < own_hi;
     const bool wl = x0 == 0, wr = x0 + V == geo.nx;               // this lane's first / last cell is a side-wall cell
     const bool side_strip = xs == 0 || xs + ROW >= geo.nx;        // (uniform) the strip holds a side wall

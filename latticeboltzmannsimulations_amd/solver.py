@@ -380,12 +380,14 @@ def _npz(path):
 
 
 def _one_rccl():
-    """PyTorch before RCCL.  The library binds RCCL with dlopen on the first lbm_comm_* call (the copy already mapped, else torch's
-    bundled one, else /opt/rocm's).  A process that created a communicator through the library and imported torch only AFTERWARDS
-    aborted in the exit handlers ("double free or corruption") -- also with torch's own librccl.so mapped by path beforehand, so it
-    is the order of initialisation of torch's bundled ROCm libraries that matters, not a second RCCL (measured:
-    tools/probes/order_probe.py, profiles/r02_logs/rccl_order.log).  Where torch is installed it is therefore imported before the
-    first RCCL call; processes that use this path exchange the communicator id through torch.distributed anyway."""
+    """PyTorch before RCCL -- belt and braces since r03.  r02: a process that created a communicator through the library and imported
+    torch only AFTERWARDS aborted in exit() ("double free or corruption").  r03 found the cause and fixed it in the library
+    (lbm_hip.hip, rccl()): RCCL had been opened RTLD_GLOBAL, which put its dependency librocm_smi64 into the global symbol scope, and a
+    library mapped later that defines the same namespace-scope std::map<amd::smi::DevInfoTypes, const char*> (the wheel's librocm_smi64,
+    /opt/rocm's libamd_smi.so) bound its initialiser and destructor to that one object: destroyed twice (backtraces
+    profiles/r03_logs/rc134_gdb.log, rc134_gdb2.log; after the fix every order exits 0: rccl_order_r03.log).  RCCL is now opened
+    RTLD_LOCAL and taken from the directory of the HIP runtime in use.  Importing torch first, where it is installed, costs nothing:
+    processes that use this path exchange the communicator id through torch.distributed anyway."""
     import importlib.util
     import sys
     if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
