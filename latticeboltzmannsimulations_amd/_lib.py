@@ -28,7 +28,7 @@ LBM_FLAG_NO_DEEP_HALO, LBM_FLAG_FRAME_UNFUSED, LBM_FLAG_FRAME_FUSED_BATCH, LBM_F
 LBM_FLAG_NT_ON, LBM_FLAG_NT_OFF, LBM_FLAG_COMM_PRIORITY_OFF, LBM_FLAG_EAGER_LAG = 16, 32, 64, 128
 LBM_FLAG_FRAME_BESIDE_ON, LBM_FLAG_FRAME_BESIDE_OFF, LBM_FLAG_FRAME_NARROW, LBM_FLAG_NO_EDGE_FIRST = 512, 1024, 2048, 4096
 LBM_FLAG_NO_EDGE_RESERVE, LBM_FLAG_NO_XCD_BANDS, LBM_FLAG_NO_TAIL_TILES, LBM_FLAG_STREAM_WALLS = 8192, 16384, 32768, 65536
-LBM_FLAG_STREAM_PAIRS = 131072
+LBM_FLAG_STREAM_PAIRS, LBM_FLAG_NO_STREAM_WALLS = 131072, 262144
 ABI_VERSION = 3        # = LBM_ABI_VERSION of include/lbm.h (tests/test_abi.py keeps them equal)
 
 

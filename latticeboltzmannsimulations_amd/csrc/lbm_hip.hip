@@ -1290,7 +1290,26 @@ static lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out)
             c->tail_tiles = !slab && c->batch == 1 && c->es == 4 && p->semantics == LBM_SEM_MRT_GPU && !(p->flags & LBM_FLAG_NO_TAIL_TILES);
             // The walls inside the streaming kernel (k_stream_walls, lbm_stream.hpp): a lone lattice in MRT_GPU.py semantics needs no
             // frame -- side-wall cells in line, the lid and the bottom row as blocks of the pipeline.
-            c->stream_walls = !slab && c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU && (p->flags & (LBM_FLAG_STREAM_WALLS | LBM_FLAG_STREAM_PAIRS));
+            // Default: where that kernel variant needs no scratch memory (r03, 4096^2 GLUPS frame -> walls inside: fp32 MRT fast 366 -> 426, strict
+            // 262 -> 292, fp64 MRT fast 171 -> 187, strict 126 -> 130, fp32 SRT 253 -> 251; the variants that spill at 128 VGPRs lose -- TRT fast 242 ->
+            // 152, SRT + closure fast 256 -> 118 -- a spill reloaded behind the prefetch waits for HBM: profiles/r03_logs/walls_variants.log).  With a
+            // device the kernel's scratch size is checked as well (hipFuncGetAttributes), so that a compiler that starts spilling one of
+            // the chosen variants falls back to the frame instead of to half the speed.
+            const bool walls_ok = !slab && c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU;
+            bool walls_pay = !p->turb && (p->collision == LBM_MRT || (p->collision == LBM_SRT && c->es == 8));
+            if (walls_ok && walls_pay && device && !(p->flags & (LBM_FLAG_STREAM_WALLS | LBM_FLAG_STREAM_PAIRS))) {
+                dispatch(c->p, [&](auto v) {
+                    using VT = decltype(v);
+                    using R = typename VT::R;
+                    if constexpr (VT::SEM == SEM_GPU) {
+                        hipFuncAttributes at;
+                        if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_stream_walls<R, VT::COLL, VT::TURB>)) != hipSuccess || at.localSizeBytes > 48)
+                            walls_pay = false;
+                    }
+                });
+            }
+            c->stream_walls = walls_ok && !(p->flags & LBM_FLAG_NO_STREAM_WALLS) &&
+                              (walls_pay || (p->flags & (LBM_FLAG_STREAM_WALLS | LBM_FLAG_STREAM_PAIRS)));
             // ... and two rows per wave (k_stream_pairs): twelve waves that all work in every iteration, 10 steps per launch by default (up
             // to SP_MAX_S), a launch that costs in proportion to its steps -- so no tile-kernel tails
             c->stream_pairs = c->stream_walls && (p->flags & LBM_FLAG_STREAM_PAIRS);

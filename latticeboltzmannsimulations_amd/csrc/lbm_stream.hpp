@@ -257,7 +257,7 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
     const R* const up_below = lds + (((q + 1) & (ST_WAVES - 1)) * 9) * ROW + lane * V;
     const R* const down_above = lds + (((q + ST_WAVES - 1) & (ST_WAVES - 1)) * 9 + 3) * ROW + lane * V;
 
-    T in[Q], outv[Q], hq, hr, rwp;
+    T in[Q], outv[Q], hq, hr;
     // address = scalar row base (SGPR pair) + unsigned 32-bit lane offset: the global_load / global_store "saddr" form, one
     // offset VGPR instead of a 64-bit address pair per plane
     auto row_base = [&](const R* p, int k, int y) { return (const char*)(p + ((long long)k * geo.plane + (long long)(y + GHY) * geo.row)); };
@@ -267,15 +267,38 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
         asm volatile("" : "+v"(off));      // (opaque: keeps base + offset from being hoisted out of the block loop as a 64-bit per-lane address)
         return (const R*)(base + (off + (unsigned)(dx * (int)sizeof(R))));
     };
-    auto load_row = [&](int y) {    // the nine pulls of a single step, straight from the lattice (level 0 -> 1)
-        if (!lane_in) return;
+    // (WALLS: every register of the prefetch is written on every path -- lanes beyond the lattice load the row's last vector, a block
+    // that does not exist gets zeros: a conditionally skipped load keeps the registers' OLD values alive through the whole block before,
+    // which at this kernel's register count means spilled, and reloaded behind the new loads, i.e. behind an HBM round trip)
+    const unsigned lane_off_ld = WALLS ? (unsigned)(GH + min(x0, max(geo.nx - V, 0))) * (unsigned)sizeof(R) : lane_off;
+    auto cell_ld = [&](const char* base, int dx) {
+        unsigned off = lane_off_ld;
+        asm volatile("" : "+v"(off));
+        return (const R*)(base + (off + (unsigned)(dx * (int)sizeof(R))));
+    };
+    auto load_row = [&](int y, bool exists) {    // the nine pulls of a single step, straight from the lattice (level 0 -> 1)
+        if (WALLS) {
+            if (exists) {
+#pragma unroll
+                for (int k = 0; k < Q; ++k) in[k] = vload<R, V, false>(cell_ld(row_base(src, k, y + cyk(k)), -cxk(k)), cxk(k) == 0);
+                if (TURB) {
+                    hq = vload<R, V, false>(cell_ld(row_base(src, K_QEQ, y), 0), true);
+                    hr = vload<R, V, false>(cell_ld(row_base(src, K_RHO, y), 0), true);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < Q; ++k) in[k] = T{};
+                hq = hr = T{};
+            }
+            return;
+        }
+        if (!lane_in || !exists) return;
 #pragma unroll
         for (int k = 0; k < Q; ++k) in[k] = vload<R, V, false>(cell(row_base(src, k, y + cyk(k)), -cxk(k)), cxk(k) == 0);
         if (TURB) {
             hq = vload<R, V, false>(cell(row_base(src, K_QEQ, y), 0), true);
             hr = vload<R, V, false>(cell(row_base(src, K_RHO, y), 0), true);
         }
-        if (WALLS && y == 0) rwp = vload<R, V, false>(cell(row_base(src, 0, -1), 0), true);   // the lid cells' parked densities (wall_rho_at)
     };
     auto post = [&](int level, bool up, bool down) __attribute__((always_inline)) {    // level reached: 1 .. S - 1
         // (tried in r03 and dropped: the downward planes, which are not read before three iterations later, written at the start of the
@@ -284,15 +307,18 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
         // registers of the early fetch spill there): the LDS phases are not what the working iterations wait for;
         // profiles/r03_logs/lds_rebalance.log)
         R* const dn = up_mine + (3 + (level & 1) * 3) * ROW;
+        // (the planes are read into values BEFORE the conditions: with the reads inside them the fp64 build keeps two of the nine
+        // output vectors in private memory -- for every row, the ordinary ones included -- and the level loop gains scratch traffic)
+        const T p2 = outv[2], p5 = outv[5], p6 = outv[6], p4 = outv[4], p7 = outv[7], p8 = outv[8];
         if (up) {
-            *reinterpret_cast<T*>(up_mine) = outv[2];
-            *reinterpret_cast<T*>(up_mine + ROW) = outv[5];
-            *reinterpret_cast<T*>(up_mine + 2 * ROW) = outv[6];
+            *reinterpret_cast<T*>(up_mine) = p2;
+            *reinterpret_cast<T*>(up_mine + ROW) = p5;
+            *reinterpret_cast<T*>(up_mine + 2 * ROW) = p6;
         }
         if (down) {
-            *reinterpret_cast<T*>(dn) = outv[4];
-            *reinterpret_cast<T*>(dn + ROW) = outv[7];
-            *reinterpret_cast<T*>(dn + 2 * ROW) = outv[8];
+            *reinterpret_cast<T*>(dn) = p4;
+            *reinterpret_cast<T*>(dn + ROW) = p7;
+            *reinterpret_cast<T*>(dn + 2 * ROW) = p8;
         }
     };
     // One block: the S updates of row y = y_first + b from the prefetched pulls, the posts, the store.  A wall row (the lid or the
@@ -312,8 +338,10 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
             R kl = (R)0, kr = (R)0;
             if (WALLS) {
                 if constexpr (WROW) {
-                    if (first) {          // from the lattice: the pulls fetched the kept slots from their parking places
-                        rw = rwp;
+                    if (first) {          // from the lattice: the pulls fetched the kept slots from their parking places; the lid cells' parked
+                        // densities (wall_rho_at) are loaded here and now -- one wait per launch in the top segments, instead of four
+                        // registers carried (and spilled) from every prefetch to every first update
+                        if (lid) rw = vload<R, V, false>(cell_ld(row_base(src, 0, -1), 0), true);
                         kl = lid ? in[7][0] : in[6][0];
                         kr = lid ? in[8][V - 1] : in[5][V - 1];
                     } else {
@@ -363,7 +391,9 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
                 kl_done = st[ROW + lane];
                 kr_done = st[2 * ROW + lane];
             }
-            if (b + ST_WAVES < nb) load_row(y_first + b + ST_WAVES);
+            // (WALLS: store first -- with outv still live the prefetch would not fit the registers, and the compiler spills a register it has
+            // just loaded, i.e. waits for HBM right here; the loads then queue behind nine stores, which costs nothing measurable)
+            if (!WALLS) load_row(y_first + b + ST_WAVES, b + ST_WAVES < nb);
             if (lane_out && y >= ya && y < yb) {
 #pragma unroll
                 for (int k = 0; k < Q; ++k) vstore<R, V, false>(const_cast<R*>(cell(row_base(dst, k, y), 0)), outv[k]);
@@ -382,13 +412,14 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
                     }
                 }
             }
+            if (WALLS) load_row(y_first + b + ST_WAVES, b + ST_WAVES < nb);
             if (S > 1) { lds_barrier(); lds_barrier(); }
         }
         for (int i = 2 * S; i < ST_WAVES; ++i) lds_barrier();
     };
 #pragma unroll
     for (int k = 0; k < Q; ++k) in[k] = T{};
-    hq = T{}; hr = T{}; rwp = T{};
+    hq = T{}; hr = T{};
     // The schedule of one wave is static: q idle iterations, then per block 16 iterations = S x (update, idle) + 16 - 2 S idle
     // ones, then idle ones up to the common total; every iteration ends with the workgroup barrier (one per iteration for every
     // wave).  Written as loops over blocks and levels -- not as one loop over iterations with a test -- so that the prefetched
@@ -396,7 +427,7 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
     const int jtot = (nb + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
     int done = q;
     for (int i = 0; i < q; ++i) lds_barrier();
-    if (q < nb) load_row(y_first + q);
+    load_row(y_first + q, q < nb);
     for (int b = q; b < nb; b += ST_WAVES) {
         const int y = y_first + b;
         if (WALLS && (y == 0 || y == geo.ny - 1)) block(b, std::true_type{});
@@ -519,7 +550,7 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
 
     T in[Q], outv[Q], rawB[Q];                                    // in: the row being updated (and A's prefetched pulls); rawB: B's prefetched pulls
     T a0, a1, a3, a4, a7, a8, b0, b1, b3, b2, b5, b6;             // resident planes (see above)
-    T hqA, hrA, hqB, hrB, rwp;                                    // Smagorinsky history of the two rows; the lid cells' parked densities
+    T hqA, hrA, hqB, hrB;                                         // Smagorinsky history of the two rows
     auto row_base = [&](const R* p, int k, int y) __attribute__((always_inline)) { return (const char*)(p + ((long long)k * geo.plane + (long long)(y + GHY) * geo.row)); };
     const unsigned lane_off = (unsigned)(GH + x0) * (unsigned)sizeof(R);
     auto cell = [&](const char* base, int dx) __attribute__((always_inline)) {
@@ -546,7 +577,6 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
                 hqA = vload<R, V, false>(cell_ld(row_base(src, K_QEQ, yA), 0), true);
                 hrA = vload<R, V, false>(cell_ld(row_base(src, K_RHO, yA), 0), true);
             }
-            rwp = vload<R, V, false>(cell_ld(row_base(src, 0, yA - 1), 0), true);   // (row 0: the lid cells' parked densities, wall_rho_at; else unused)
             const int yBc = min(yB, y_end - 1);                                     // (no B row: the A row's data again, a dummy nobody reads)
 #pragma unroll
             for (int k = 0; k < Q; ++k) rawB[k] = vload<R, V, false>(cell_ld(row_base(src, k, yBc + cyk(k)), -cxk(k)), cxk(k) == 0);
@@ -557,7 +587,7 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
         } else {
 #pragma unroll
             for (int k = 0; k < Q; ++k) { in[k] = T{}; rawB[k] = T{}; }
-            hqA = hrA = hqB = hrB = rwp = T{};
+            hqA = hrA = hqB = hrB = T{};
         }
     };
     // B's prefetched pulls wait for their turn in LDS, not in registers: through A's first update they would push the pair over the 168
@@ -579,8 +609,8 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
             T rw = T{};
             R kl = (R)0, kr = (R)0;
             if (wrow) {
-                if (first) {
-                    rw = rwp;
+                if (first) {      // (the lid cells' parked densities, wall_rho_at: loaded here and now, once per launch in the top segments)
+                    if (lid) rw = vload<R, V, false>(cell_ld(row_base(src, 0, -1), 0), true);
                     kl = lid ? in[7][0] : in[6][0];
                     kr = lid ? in[8][V - 1] : in[5][V - 1];
                 } else {
@@ -625,7 +655,7 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
     };
 #pragma unroll
     for (int k = 0; k < Q; ++k) { in[k] = T{}; rawB[k] = T{}; }
-    hqA = hrA = hqB = hrB = rwp = T{};
+    hqA = hrA = hqB = hrB = T{};
     a0 = a1 = a3 = a4 = a7 = a8 = b0 = b1 = b3 = b2 = b5 = b6 = T{};
     // The schedule of a wave: 2 wv idle iterations, then per pair 2 S working iterations (A, B, A, B, ...) and 2 (W - S) idle ones
     // (the next pair is loaded at their start), then idle ones up to the common total; one workgroup barrier per iteration.
@@ -645,11 +675,12 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
         // what follows an update of A / B that reached level l1 = l + 1
         auto after_A = [&](int l1) __attribute__((always_inline)) {
             a0 = outv[0]; a1 = outv[1]; a3 = outv[3]; a4 = outv[4]; a7 = outv[7]; a8 = outv[8];
+            const T p2 = outv[2], p5 = outv[5], p6 = outv[6];     // (read before the conditions: see stream_segment's post)
             if (l1 < S) {
                 if (!lidA) {
-                    *reinterpret_cast<T*>(post_mine) = outv[2];
-                    *reinterpret_cast<T*>(post_mine + ROW) = outv[5];
-                    *reinterpret_cast<T*>(post_mine + 2 * ROW) = outv[6];
+                    *reinterpret_cast<T*>(post_mine) = p2;
+                    *reinterpret_cast<T*>(post_mine + ROW) = p5;
+                    *reinterpret_cast<T*>(post_mine + 2 * ROW) = p6;
                 }
             } else {
                 store_row(yA, hqA, hrA);
@@ -658,12 +689,13 @@ __device__ __forceinline__ void stream_pairs_segment(const R* __restrict__ src, 
         };
         auto after_B = [&](int l1) __attribute__((always_inline)) {
             b0 = outv[0]; b1 = outv[1]; b3 = outv[3]; b2 = outv[2]; b5 = outv[5]; b6 = outv[6];
+            const T p4 = outv[4], p7 = outv[7], p8 = outv[8];
             if (l1 < S) {
                 if (!botB) {
                     R* const dn = post_mine + (3 + (l1 & 1) * 3) * ROW;
-                    *reinterpret_cast<T*>(dn) = outv[4];
-                    *reinterpret_cast<T*>(dn + ROW) = outv[7];
-                    *reinterpret_cast<T*>(dn + 2 * ROW) = outv[8];
+                    *reinterpret_cast<T*>(dn) = p4;
+                    *reinterpret_cast<T*>(dn + ROW) = p7;
+                    *reinterpret_cast<T*>(dn + 2 * ROW) = p8;
                 }
             }
             lds_barrier();

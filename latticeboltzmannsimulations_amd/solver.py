@@ -36,8 +36,9 @@ def _tuning(t):
            "comm_priority": L.LBM_FLAG_COMM_PRIORITY_OFF, "frame_wide": L.LBM_FLAG_FRAME_NARROW, "edge_first": L.LBM_FLAG_NO_EDGE_FIRST,
            "edge_reserve": L.LBM_FLAG_NO_EDGE_RESERVE, "xcd_bands": L.LBM_FLAG_NO_XCD_BANDS,
            "tail_tiles": L.LBM_FLAG_NO_TAIL_TILES}
-    on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG,
-          "stream_walls": L.LBM_FLAG_STREAM_WALLS, "stream_pairs": L.LBM_FLAG_STREAM_PAIRS}
+    on = {"frame_fused_batch": L.LBM_FLAG_FRAME_FUSED_BATCH, "eager_lag": L.LBM_FLAG_EAGER_LAG, "stream_pairs": L.LBM_FLAG_STREAM_PAIRS}
+    if "stream_walls" in t:     # (three states: True / False force it, absent = the library's choice per operator variant)
+        flags |= L.LBM_FLAG_STREAM_WALLS if t.pop("stream_walls") else L.LBM_FLAG_NO_STREAM_WALLS
     for k, bit in off.items():
         if not t.pop(k, True):
             flags |= bit

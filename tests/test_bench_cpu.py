@@ -96,7 +96,7 @@ def test_every_rank_of_the_multi_gpu_bench_plans_the_same_protocol():
                 NY = bench.slab_of(cfg, scaling, world, 0)[0]
                 assert min(n for _, n in partition_rows(NY, world)) >= 2 * plans[0]["frame"]
     one = bench.rank_plan("c3", "strong", 1, 0, "auto", "fast", 20)
-    assert one["slab"] == 0 and one["kernel"] == "k_stream" and one["units"] == [1, 8, 8, 3]
+    assert one["slab"] == 0 and one["kernel"] == "k_stream_walls" and one["units"] == [1, 8, 8, 3]
     # 768 x 1535 rows cut in two: 768 and 767 rows sit on opposite sides of the tile kernel's size threshold
     parts = partition_rows(1535, 2)
     with_min = [launch_plan(768, 1535, 1000.0, steps=12, rows=r, min_rows=min(n for _, n in parts)) for r in parts]

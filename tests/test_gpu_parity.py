@@ -199,10 +199,11 @@ def test_streaming_kernel_is_bit_identical_to_oracle(sem, coll, turb, dtype, mod
     neighbour rows through LDS, x neighbours by DPP.  Sizes with one and several strips (partial last strip), one and several
     row segments, every steps-per-launch setting 2 .. 8 (frame widths 4 / 8 / 12), call lengths that leave every remainder
     (tail units of 3 .. 7 steps, single steps), fields read after units of every length (lagged lattice recomputed by the same
-    kernel).  mode: "frame" = the default (k_stream: the cells next to the walls as a frame of single-step passes); the two r03
-    experiments kept for A/B, both bit-identical too: "walls" = the walls inside the streaming kernel (k_stream_walls: side walls on the
-    lane shifts, lid / bottom row as rows of the pipeline, corner kept slots carried; a lone lattice in MRT_GPU.py semantics) and "pairs" =
-    that with two rows per wave, twelve waves, up to 10 steps per launch (k_stream_pairs)."""
+    kernel).  mode: "frame" = k_stream, the cells next to the walls as a frame of single-step passes (slabs, MRT.py semantics, the
+    operator variants that would spill); "walls" = the walls inside the streaming kernel (k_stream_walls, r03: side walls on the lane
+    shifts, lid / bottom row as rows of the pipeline, corner kept slots carried; the default for a lone MRT / fp64 SRT lattice in
+    MRT_GPU.py semantics); "pairs" = that with two rows per wave, twelve waves, up to 10 steps per launch (k_stream_pairs, an r03
+    experiment kept for A/B).  All three bit-identical to the oracle."""
     if mode != "frame" and sem == "mrt_py":
         pytest.skip("the walls inside the streaming kernel: MRT_GPU.py semantics only (MRT.py lattices keep the frame: the other leg)")
     walls = mode != "frame"
@@ -214,7 +215,7 @@ def test_streaming_kernel_is_bit_identical_to_oracle(sem, coll, turb, dtype, mod
         o = CavityOracleC(nx, ny, 1000.0, semantics=sem, collision=coll, dtype=dtype, turb=turb)
         # (the wall frame inside the launch or as a kernel of its own beside the streaming workgroups: alternate, whatever the default)
         with CavitySolver(nx, ny, 1000.0, RT=coll, semantics=sem, dtype=dtype, turb=turb, kernel="stream",
-                          tuning=dict(tb_steps=tbs, frame_beside=bool((nx // 4) % 2), stream_walls=mode == "walls", stream_pairs=mode == "pairs")) as s:
+                          tuning=dict(tb_steps=tbs, frame_beside=bool((nx // 4) % 2), stream_walls=mode != "frame", stream_pairs=mode == "pairs")) as s:
             assert s.describe()["kernel"] == {"pairs": "k_stream_pairs", "walls": "k_stream_walls", "frame": "k_stream"}[mode], s.describe()
             for n in (1, 8, 19, 3, 7, 12):
                 o.step(n); s.step(n)
@@ -923,7 +924,7 @@ def test_streaming_kernel_fast_arithmetic_every_instantiation(coll, turb, dtype)
     with CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="generic", arith="fast") as g, \
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast", tuning=dict(tb_steps=8, stream_pairs=True)) as s8, \
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast",
-                         tuning=dict(tb_steps=3, frame_beside=True, tail_tiles=False)) as s3, \
+                         tuning=dict(tb_steps=3, frame_beside=True, tail_tiles=False, stream_walls=False)) as s3, \
             CavitySolver(nx, ny, 5000.0, RT=coll, dtype=dtype, turb=turb, kernel="stream", arith="fast",
                          tuning=dict(tb_steps=5, stream_walls=True)) as sw:
         for n in calls:
