@@ -78,17 +78,20 @@ def level_loop(lines):
 def main():
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for unit, dtype in (("lbm_stream_f32.hip", "float32"), ("lbm_stream_f64.hip", "float64")):
+        for unit, dtype in (("lbm_stream_f32.hip", "float32"), ("lbm_stream_f64.hip", "float64"),
+                            ("lbm_streamw_f32.hip", "float32"), ("lbm_streamw_f64.hip", "float64")):   # k_stream, k_stream_walls (r03)
             asm = os.path.join(tmp, unit + ".s")
             subprocess.check_call([HIPCC] + FLAGS + [os.path.join(CSRC, unit), "-o", asm], stderr=subprocess.DEVNULL)
             text = open(asm).read().split("\n")
-            starts = [(i, m.group(1)) for i, ln in enumerate(text) if (m := re.match(r"^(_Z8k_stream\w+):", ln))]
+            starts = [(i, m.group(1)) for i, ln in enumerate(text) if (m := re.match(r"^(_Z\d+k_stream\w+):", ln))]
             for n, (i, sym) in enumerate(starts):
                 end = starts[n + 1][0] if n + 1 < len(starts) else len(text)
                 m = re.match(r"_Z8k_streamI([fd])Li(\d)ELi(\d)ELb([01])E", sym)
-                if not m:
+                mw = re.match(r"_Z14k_stream_wallsI([fd])Li(\d)ELb([01])E", sym)
+                if not m and not mw:
                     continue
-                coll, sem, turb = int(m.group(2)), int(m.group(3)), int(m.group(4))
+                kname = "k_stream" if m else "k_stream_walls"
+                coll, sem, turb = (int(m.group(2)), int(m.group(3)), int(m.group(4))) if m else (int(mw.group(2)), 1, int(mw.group(3)))
                 if sem != 1:
                     continue                      # (MRT.py semantics shares the tile code; report MRT_GPU)
                 body = text[i:end]
@@ -104,7 +107,7 @@ def main():
                     counts[cls] = counts.get(cls, 0) + 1
                     cycles += c
                 rt, arith = COLL[coll]
-                key = f"k_stream:{dtype}:{rt}:{arith}:turb{turb}"
+                key = f"{kname}:{dtype}:{rt}:{arith}:turb{turb}"
                 out[key] = {"issue_cycles_per_wave_update": cycles, "instructions": counts,
                             "source": "tools/valu_mix.py: level loop of " + sym + ", issue costs of tools/valu_issue.hip (profiles/r02_logs/valu_issue.log)"}
     path = os.path.join(ROOT, "profiles", "valu_mix.json")
