@@ -48,19 +48,13 @@ def sources():
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into liblbm_hip.so next to this file (in-tree).  The translation units (host code + C ABI,
-    and the explicit instantiations of the multi-step tile kernel for float and for double) are compiled in parallel into
-    csrc/_obj/ and linked; LBM_SINGLE_TU=1 compiles lbm_hip.hip alone, instantiating everything there."""
+    """Compile csrc/*.hip for gfx950 into liblbm_hip.so next to this file (in-tree).  The translation units (four of host code +
+    C ABI: lbm_hip / lbm_plan / lbm_launch / lbm_comm; the explicit instantiations of the tile and streaming kernels for float and
+    for double) are compiled in parallel into csrc/_obj/ and linked."""
     srcs = sources()
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
-    if os.environ.get("LBM_SINGLE_TU"):
-        cmd = [HIPCC] + HIPCC_FLAGS + ["-DLBM_SINGLE_TU", "-o", LIB_PATH, os.path.join(_CSRC, "lbm_hip.hip")] + LINK_FLAGS
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(_CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
@@ -72,7 +66,7 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    with ThreadPoolExecutor(max_workers=len(units)) as pool:
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as pool:
         list(pool.map(compile_one, zip(units, objs)))
     cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + LINK_FLAGS
     if verbose:

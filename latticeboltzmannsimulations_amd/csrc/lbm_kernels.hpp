@@ -1,5 +1,5 @@
 // lbm_kernels.hpp -- the __global__ kernels of liblbm_hip.so (templates; see lbm_device.hpp for the per-cell operators).
-// Included by lbm_hip.hip (host code + C ABI) and by lbm_tiles_f32.hip / lbm_tiles_f64.hip, which hold the explicit
+// Included by the host units (through lbm_host.hpp) and by lbm_tiles_f32.hip / lbm_tiles_f64.hip, which hold the explicit
 // instantiations of the multi-step tile kernel so that the three translation units compile in parallel (lbm_tiles_inst.hpp).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -770,7 +770,6 @@ __global__ __launch_bounds__(SP_NT) void k_stream_pairs(const R* __restrict__ sr
     stream_pairs_segment<R, COLL, TURB>(src, dst, geo, w, lds, S, xs, ya, yb, own_lo, own_hi);
 }
 
-#ifndef LBM_SINGLE_TU
 #ifndef LBM_STREAMP_EXTERN
 #define LBM_STREAMP_EXTERN extern
 #endif
@@ -787,11 +786,9 @@ LBM_STREAMP_ALL(float)
 #if !defined(LBM_STREAM_ONLY_F32) && !defined(LBM_STREAMP_SKIP)
 LBM_STREAMP_ALL(double)
 #endif
-#endif
 
 // explicit instantiations live in lbm_stream_f32.hip / lbm_stream_f64.hip and lbm_streamw_f32.hip / lbm_streamw_f64.hip
 // (LBM_STREAM_EXTERN / LBM_STREAMW_EXTERN empty there)
-#ifndef LBM_SINGLE_TU
 #ifndef LBM_STREAMW_EXTERN
 #define LBM_STREAMW_EXTERN extern
 #endif
@@ -808,9 +805,7 @@ LBM_STREAMW_ALL(float)
 #if !defined(LBM_STREAM_ONLY_F32) && !defined(LBM_STREAMW_SKIP)
 LBM_STREAMW_ALL(double)
 #endif
-#endif
 
-#ifndef LBM_SINGLE_TU
 #ifndef LBM_STREAM_EXTERN
 #define LBM_STREAM_EXTERN extern
 #endif
@@ -829,4 +824,3 @@ LBM_STREAM_ALL(float)
 #if !defined(LBM_STREAM_ONLY_F32) && !defined(LBM_STREAM_SKIP)
 LBM_STREAM_ALL(double)
 #endif
-#endif  // LBM_SINGLE_TU

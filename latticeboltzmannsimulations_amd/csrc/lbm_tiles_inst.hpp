@@ -1,8 +1,6 @@
-// lbm_tiles_inst.hpp -- every instantiation of the multi-step tile kernel the dispatcher of lbm_hip.hip can ask for
-// (lbm_hip.hip: dispatch(), launch_deep()).  LBM_TILE_EXTERN is `extern` in lbm_hip.hip (declarations only: the kernels are
-// compiled in lbm_tiles_f32.hip / lbm_tiles_f64.hip) and empty there (explicit instantiation definitions).  With
-// -DLBM_SINGLE_TU nothing is declared and lbm_hip.hip instantiates what it uses itself (one slow translation unit).
-#ifndef LBM_SINGLE_TU
+// lbm_tiles_inst.hpp -- every instantiation of the multi-step tile kernel the dispatcher can ask for (lbm_host.hpp: dispatch();
+// lbm_launch.hip: launch_deep()).  LBM_TILE_EXTERN is `extern` in the host units (declarations only: the kernels are
+// compiled in lbm_tiles_f32.hip / lbm_tiles_f64.hip) and empty there (explicit instantiation definitions).
 #ifndef LBM_TILE_EXTERN
 #define LBM_TILE_EXTERN extern
 #endif
@@ -26,4 +24,3 @@ LBM_TILE_ALL(float)
 #if !defined(LBM_TILES_ONLY_F32)
 LBM_TILE_ALL(double)
 #endif
-#endif  // LBM_SINGLE_TU

@@ -383,7 +383,7 @@ def _npz(path):
 def _one_rccl():
     """PyTorch before RCCL -- belt and braces since r03.  r02: a process that created a communicator through the library and imported
     torch only AFTERWARDS aborted in exit() ("double free or corruption").  r03 found the cause and fixed it in the library
-    (lbm_hip.hip, rccl()): RCCL had been opened RTLD_GLOBAL, which put its dependency librocm_smi64 into the global symbol scope, and a
+    (lbm_comm.hip, rccl()): RCCL had been opened RTLD_GLOBAL, which put its dependency librocm_smi64 into the global symbol scope, and a
     library mapped later that defines the same namespace-scope std::map<amd::smi::DevInfoTypes, const char*> (the wheel's librocm_smi64,
     /opt/rocm's libamd_smi.so) bound its initialiser and destructor to that one object: destroyed twice (backtraces
     profiles/r03_logs/rc134_gdb.log, rc134_gdb2.log; after the fix every order exits 0: rccl_order_r03.log).  RCCL is now opened

@@ -40,7 +40,7 @@ def test_traffic_table_has_the_default_bench_entry():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     for key in ("c3:1:auto:fast", "c3:1:auto:strict", "c3:1:vec:strict", "c3:1:tb:fast"):
         assert t[key]["hbm_bytes_per_launch"] > 0 and t[key]["steps_per_launch"] >= 1 and t[key]["source"] and t[key]["kernel"], key
-    assert t["c3:1:auto:fast"]["kernel"] == "k_stream" and t["c3:1:auto:fast"]["steps_per_launch"] == 8
+    assert t["c3:1:auto:fast"]["kernel"] == "k_stream_walls" and t["c3:1:auto:fast"]["steps_per_launch"] == 8
     # a multi-step launch moves about one read + one write of the lattice; so does a single step
     for key in ("c3:1:auto:fast", "c3:1:auto:strict", "c3:1:vec:strict", "c3:1:tb:fast"):
         assert 0.95 < t[key]["hbm_bytes_per_launch"] / (4096 * 4096 * 72) < 1.5, key
