@@ -122,7 +122,11 @@ __host__ __device__ constexpr int stream_rim(int S, int V) { return (S + V - 1) 
 // (s_waitcnt vmcnt(0)): here that would put the HBM round trip of the one wave that has just stored its row and prefetched the
 // next on the critical path of all sixteen, every iteration (measured: 2.4 us per iteration instead of 0.7).  The prefetched
 // registers are waited for where they are used (the compiler's own s_waitcnt vmcnt before the first update of the block).
+#ifdef LBM_EXPERIMENT_NO_BARRIER   // timing experiment only (tools/probes): the waves run free, the results are garbage
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // ---- the walls inside the streaming kernel (k_stream_walls: a lone lattice in MRT_GPU.py semantics) --------------------------------
 // Without them the cells within F of a wall are a FRAME advanced by S dependent single-step passes of the general one-cell
