@@ -264,7 +264,11 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
     T in[Q], outv[Q], hq, hr;
     // address = scalar row base (SGPR pair) + unsigned 32-bit lane offset: the global_load / global_store "saddr" form, one
     // offset VGPR instead of a 64-bit address pair per plane
+#ifdef LBM_EXP_NO_HBM
+    auto row_base = [&](const R* p, int k, int y) { return (const char*)(p + ((long long)k * geo.plane + (long long)((y & 63) + GHY) * geo.row)); };
+#else
     auto row_base = [&](const R* p, int k, int y) { return (const char*)(p + ((long long)k * geo.plane + (long long)(y + GHY) * geo.row)); };
+#endif
     const unsigned lane_off = (unsigned)(GH + x0) * (unsigned)sizeof(R);
     auto cell = [&](const char* base, int dx) {
         unsigned off = lane_off;
@@ -314,11 +318,17 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
         // (the planes are read into values BEFORE the conditions: with the reads inside them the fp64 build keeps two of the nine
         // output vectors in private memory -- for every row, the ordinary ones included -- and the level loop gains scratch traffic)
         const T p2 = outv[2], p5 = outv[5], p6 = outv[6], p4 = outv[4], p7 = outv[7], p8 = outv[8];
+#ifdef LBM_EXP_NO_LDS
+        if (geo.nx < 0)
+#endif
         if (up) {
             *reinterpret_cast<T*>(up_mine) = p2;
             *reinterpret_cast<T*>(up_mine + ROW) = p5;
             *reinterpret_cast<T*>(up_mine + 2 * ROW) = p6;
         }
+#ifdef LBM_EXP_NO_LDS
+        if (geo.nx < 0)
+#endif
         if (down) {
             *reinterpret_cast<T*>(dn) = p4;
             *reinterpret_cast<T*>(dn + ROW) = p7;
@@ -362,7 +372,12 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
                     if (wr) { in[3][V - 1] = (R)0 + in[1][V - 1]; in[6][V - 1] = (R)0 + in[8][V - 1]; in[7][V - 1] = (R)0 + in[5][V - 1]; }
                 }
             }
+#ifdef LBM_EXP_NO_COLLIDE
+#pragma unroll
+            for (int k = 0; k < Q; ++k) outv[k] = in[k];
+#else
             collide_vec<R, COLL, V, TURB>(in, w, outv, hq, hr, wl && kind == 0, wr && kind == 0, kind);
+#endif
             if constexpr (WALLS && WROW) {        // (the last level's values are read back from these slots when the row is stored)
                 if (lid) *reinterpret_cast<T*>(st + lane * V) = rw;
                 st[ROW + lane] = kl;
@@ -376,9 +391,13 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
         lds_barrier();
         for (int l = 1; l < S; ++l) {                                             // level l -> l + 1
             const R* const dn = down_above + (l & 1) * 3 * ROW;
+#ifdef LBM_EXP_NO_LDS
+            build_in<R, V, WALLS>(in, outv[0], outv[1], outv[3], outv[2], outv[5], outv[6], outv[4], outv[7], outv[8]);
+#else
             build_in<R, V, WALLS>(in, outv[0], outv[1], outv[3], *reinterpret_cast<const T*>(up_below), *reinterpret_cast<const T*>(up_below + ROW),
                                   *reinterpret_cast<const T*>(up_below + 2 * ROW), *reinterpret_cast<const T*>(dn), *reinterpret_cast<const T*>(dn + ROW),
                                   *reinterpret_cast<const T*>(dn + 2 * ROW));
+#endif
             update(false);
             if (l + 1 < S) {
                 post(l + 1, up, down);
