@@ -98,8 +98,11 @@ int launch_frame_multi(lbm_ctx* c, int from, int to, int S, hipStream_t s, bool 
 }
 
 int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_frame) {
-    if (c->stream_walls) {   // the whole lattice, walls included, in one launch of the streaming kernel: no frame at all
-        if (!with_frame) return fail(c, LBM_ERR_STATE, "internal: the streaming kernel with the walls inside takes the whole lattice");
+    if (c->stream_walls) {
+        // walls included, no frame at all: the whole lattice in one launch (with_frame), or a slab's rows between its edge bands
+        const bool slab = is_slab(c);
+        if (slab == with_frame) return fail(c, LBM_ERR_STATE, "internal: the streaming kernel with the walls inside takes a whole lone lattice or a slab's bulk rows");
+        const int ybeg = has_neighbour(c, LBM_SIDE_LOW) ? c->tb_f : 0, yend = c->geo.ny - (has_neighbour(c, LBM_SIDE_HIGH) ? c->tb_f : 0);
         dispatch(c->p, [&](auto v) {
             using VT = decltype(v);
             using R = typename VT::R;
@@ -108,6 +111,9 @@ int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_
                 if (c->stream_pairs)
                     hipLaunchKernelGGL((k_stream_pairs<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * pl.nsegy), dim3(64 * pairs_waves(S)), 0, s,
                                        (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, c->xcd_bands ? 1 : 0);
+                else if (slab)
+                    hipLaunchKernelGGL((k_stream_walls_slab<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s, (const R*)c->lat[from],
+                                       (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, c->xcd_bands ? 1 : 0, ybeg, yend, 0, 0, 0, 0);
                 else
                     hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * pl.nsegy), dim3(ST_NT), 0, s, (const R*)c->lat[from],
                                        (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, c->xcd_bands ? 1 : 0);
@@ -143,6 +149,20 @@ int launch_stream(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool with_
 // streaming segment that starts in the neighbour's rows of the deep halo.  It writes every row the next exchange sends.
 // extra: rows of the neighbours' side owned on top (1 for the lagged lattice, see frame_passes).
 int launch_stream_edges(lbm_ctx* c, int from, int to, hipStream_t s, int S, bool lo, bool hi, int extra) {
+    if (c->stream_walls) {   // the walls inside: the edge launch is the interface bands alone, over the whole width (side-wall cells in line)
+        dispatch(c->p, [&](auto v) {
+            using VT = decltype(v);
+            using R = typename VT::R;
+            if constexpr (VT::SEM == SEM_GPU) {
+                const StreamPlan pl = plan_stream(c, S);
+                hipLaunchKernelGGL((k_stream_walls_slab<R, VT::COLL, VT::TURB>), dim3(pl.nstrips * ((lo ? 1 : 0) + (hi ? 1 : 0))), dim3(ST_NT), 0, s,
+                                   (const R*)c->lat[from], (R*)c->lat[to], c->geo, relax_of<R>(c->p), S, pl.nstrips, pl.H, 0, 0, 0,
+                                   (lo ? 1 : 0) | (hi ? 2 : 0), lo ? 1 + extra : 0, hi ? 1 + extra : 0, c->tb_f);
+            }
+        });
+        HIP_TRY(c, hipGetLastError());
+        return LBM_OK;
+    }
     const bool use_lds = frame_lds_fits(c, S, false, extra, ST_LDS_BYTES);
     if (!use_lds) {
         const int rc = ensure_scratch(c, S - 1);
@@ -179,6 +199,9 @@ int warm_stream(lbm_ctx* c) {
                 if (c->stream_pairs)
                     hipLaunchKernelGGL((k_stream_pairs<R, VT::COLL, VT::TURB>), dim3(1), dim3(64 * pairs_waves(c->tb_steps)), 0, c->s_compute, (const R*)c->lat[0],
                                        (R*)c->lat[1], c->geo, relax_of<R>(c->p), c->tb_steps, 1, 0, 0);
+                else if (is_slab(c))   // (rows [0, 0): empty)
+                    hipLaunchKernelGGL((k_stream_walls_slab<R, VT::COLL, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
+                                       c->geo, relax_of<R>(c->p), c->tb_steps, 1, 0, 0, 0, 0, 0, 0, 0, 0);
                 else
                     hipLaunchKernelGGL((k_stream_walls<R, VT::COLL, VT::TURB>), dim3(1), dim3(ST_NT), 0, c->s_compute, (const R*)c->lat[0], (R*)c->lat[1],
                                        c->geo, relax_of<R>(c->p), c->tb_steps, 1, 0, 0);
@@ -321,7 +344,7 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // this unit's tile kernel needs the previous unit's frame
     int from = a;
     const bool has_lo = has_neighbour(c, LBM_SIDE_LOW), has_hi = has_neighbour(c, LBM_SIDE_HIGH);
-    if (c->frame_fused && S >= 3 && c->stream && deep) {
+    if ((c->frame_fused || c->stream_walls) && S >= 3 && c->stream && deep) {
         // The streaming kernel between slabs: the edge launch (interface rows + column strips, everything the next exchange sends)
         // here, the bulk launch below.  Both become ready when the previous bulk launch ends, and the bulk launch -- one
         // workgroup per CU for its whole run -- must not take the CUs first: the edge workgroups would run last, and the next
@@ -406,7 +429,7 @@ int prev_lattice(lbm_ctx* c, int* which) {
             const bool lo = has_neighbour(c, LBM_SIDE_LOW), hi = has_neighbour(c, LBM_SIDE_HIGH);
             // one row more than a launch unit computes: the field export pulls the slab's first / last row from the first ghost
             // rows of this lattice (the unit received S = k + 1 rows per side: enough)
-            if (c->frame_fused && c->stream && c->deep_halo) rc = launch_stream_edges(c, from, LAT_LAG, c->s_compute, k, lo, hi, 1);
+            if ((c->frame_fused || c->stream_walls) && c->stream && c->deep_halo) rc = launch_stream_edges(c, from, LAT_LAG, c->s_compute, k, lo, hi, 1);
             else if (c->frame_fused) rc = launch_frame_multi(c, from, LAT_LAG, k, c->s_compute, lo, hi, 1);
             else {
                 rc = ensure_scratch(c, 2);

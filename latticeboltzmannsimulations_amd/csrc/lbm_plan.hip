@@ -18,8 +18,11 @@ bool frame_lds_fits(const lbm_ctx* c, int S, bool deep_rows, int extra, long lon
 int pairs_waves(int S) { return std::min(SP_MAX_WAVES, S + 2); }
 StreamPlan plan_stream_on(const lbm_ctx* c, int S, int ncu, long long* cost_out) {
     const int V = 16 / c->es, Rr = stream_rim(S, V), TXu = 64 * V - 2 * Rr, F = c->stream_walls ? 0 : c->tb_f;
-    const int cols = c->geo.nx - 2 * F, rows = c->geo.ny - 2 * F;
-    // (with the walls inside: strips over the whole width, no rim at a wall; segments over the whole height)
+    const int cols = c->geo.nx - 2 * F;
+    // (with the walls inside: strips over the whole width, no rim at a wall; segments over the whole height -- of a slab: over the rows
+    // between its edge bands, tb_f rows next to each interface)
+    const int rows = c->stream_walls ? c->geo.ny - c->tb_f * ((has_neighbour(c, LBM_SIDE_LOW) ? 1 : 0) + (has_neighbour(c, LBM_SIDE_HIGH) ? 1 : 0))
+                                     : c->geo.ny - 2 * F;
     StreamPlan best{c->stream_walls ? stream_walls_strips(c->geo.nx, S, V) : (cols + TXu - 1) / TXu, 1, rows};
     long long best_cost = -1;
     for (int n = 1; n <= 256 && n * 8 <= std::max(rows, 8); ++n) {
@@ -44,16 +47,30 @@ StreamPlan plan_stream_on(const lbm_ctx* c, int S, int ncu, long long* cost_out)
 StreamPlan plan_stream(const lbm_ctx* c, int S) {
     long long cost0 = 0;
     const StreamPlan p0 = plan_stream_on(c, S, c->ncu, &cost0);
-    if (!(is_slab(c) && c->deep_halo && c->frame_fused && c->edge_reserve) || S < 3) return p0;
+    if (!(is_slab(c) && c->deep_halo && (c->frame_fused || c->stream_walls) && c->edge_reserve) || S < 3) return p0;
     if ((long long)p0.nstrips * p0.nsegy > c->ncu) return p0;     // several rounds: the bulk launch is released behind the edge launch instead
     const int nb = (has_neighbour(c, LBM_SIDE_LOW) ? 1 : 0) + (has_neighbour(c, LBM_SIDE_HIGH) ? 1 : 0), L = c->frame_seg;
-    const long long n_edge = (long long)nb * p0.nstrips + 2LL * ((c->geo.ny + L - 1) / L) + (2LL - nb) * ((c->geo.nx + L - 1) / L);
+    const long long n_edge = c->stream_walls ? (long long)nb * p0.nstrips     // (the walls inside: the interface bands alone)
+                                             : (long long)nb * p0.nstrips + 2LL * ((c->geo.ny + L - 1) / L) + (2LL - nb) * ((c->geo.nx + L - 1) / L);
     const long long edge_it = (c->tb_f + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
-    if (2 * cost0 > 3 * edge_it) return p0;   // (measured: a bulk launch longer than ~1.5 edge workgroups overlaps them well enough as it is)
+    // (measured: a bulk launch longer than ~1.5 edge workgroups overlaps the frame variant's ~100 short edge workgroups well enough as
+    // it is.  With the walls inside the edge launch is the 2 x nstrips band workgroups alone, each of which holds a CU -- all its LDS --
+    // for edge_it iterations, and the bulk workgroups that find no CU start that much later: leaving them room pays up to a bulk launch
+    // of ~3 edge workgroups -- 4096 x 512 fp32 slab in loopback 141 -> 177 GLUPS, 4096 x 1024 210 -> 244, 4096 x 2048 289 -> 274:
+    // profiles/r03_logs/slab_walls.log)
+    if (c->stream_walls ? cost0 > 3 * edge_it : 2 * cost0 > 3 * edge_it) return p0;
     StreamPlan best = p0;
     long long best_cost = cost0 + edge_it * ((n_edge + c->ncu - 1) / c->ncu);
-    for (int div = 1; div <= 3; ++div) {
-        const long long r = (n_edge + div - 1) / div;
+    // (workgroups go to the eight XCDs in turn, whatever is free where: "room" is per XCD -- kernel trace of the 4096 x 1024 slab, 34 + 221
+    // workgroups on 256 CUs: XCD 0 is dealt 5 + 28 and its last bulk workgroup starts when an edge workgroup ends, 43 us late -- so the
+    // CUs left to the edge workgroups are counted in eighths, rounded up)
+    const long long xcd = c->stream_walls ? 8 : 1;
+    auto per_xcd = [&](long long n) { return (n + xcd - 1) / xcd * xcd; };
+    if (c->stream_walls && per_xcd((long long)p0.nstrips * p0.nsegy) + per_xcd(n_edge) <= c->ncu) best_cost = std::max(cost0, edge_it);   // (room for both)
+    // (div > 1: the edge workgroups in several rounds on fewer CUs -- the frame variant's many short ones; the band workgroups of the
+    // walls variant are all dispatched at once, ahead of the bulk launch, and hold what they get)
+    for (int div = 1; div <= (c->stream_walls ? 1 : 3); ++div) {
+        const long long r = per_xcd((n_edge + div - 1) / div);
         if (r < 1 || r > c->ncu / 2) continue;
         long long cb = 0;
         const StreamPlan p = plan_stream_on(c, S, c->ncu - (int)r, &cb);
@@ -242,8 +259,11 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
             // 262 -> 292, fp64 MRT fast 171 -> 187, strict 126 -> 130, fp32 SRT 253 -> 251; the variants that spill at 128 VGPRs lose -- TRT fast 242 ->
             // 152, SRT + closure fast 256 -> 118 -- a spill reloaded behind the prefetch waits for HBM: profiles/r03_logs/walls_variants.log).  With a
             // device the kernel's scratch size is checked as well (hipFuncGetAttributes), so that a compiler that starts spilling one of
-            // the chosen variants falls back to the frame instead of to half the speed.
-            const bool walls_ok = !slab && c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU;
+            // the chosen variants falls back to the frame instead of to half the speed (the bound, 64 B per lane, admits the strict MRT
+            // operator's 52 B: a dozen registers parked once per BLOCK, outside the level loop -- what costs is a reload inside it).
+            // r03, second half: a slab too (its deep halo is complete rows of the same lattice format, side-wall cells included): the edge
+            // launch shrinks to the interface bands, the column strips and the lid / bottom row strip of the frame go
+            const bool walls_ok = c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU && (!slab || !(p->flags & LBM_FLAG_NO_DEEP_HALO));
             bool walls_pay = !p->turb && (p->collision == LBM_MRT || (p->collision == LBM_SRT && c->es == 8));
             if (walls_ok && walls_pay && device && !(p->flags & (LBM_FLAG_STREAM_WALLS | LBM_FLAG_STREAM_PAIRS))) {
                 dispatch(c->p, [&](auto v) {
@@ -251,7 +271,9 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
                     using R = typename VT::R;
                     if constexpr (VT::SEM == SEM_GPU) {
                         hipFuncAttributes at;
-                        if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_stream_walls<R, VT::COLL, VT::TURB>)) != hipSuccess || at.localSizeBytes > 48)
+                        const void* kern = slab ? reinterpret_cast<const void*>(&k_stream_walls_slab<R, VT::COLL, VT::TURB>)
+                                                : reinterpret_cast<const void*>(&k_stream_walls<R, VT::COLL, VT::TURB>);
+                        if (hipFuncGetAttributes(&at, kern) != hipSuccess || at.localSizeBytes > 64)
                             walls_pay = false;
                     }
                 });
@@ -260,7 +282,7 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
                               (walls_pay || (p->flags & (LBM_FLAG_STREAM_WALLS | LBM_FLAG_STREAM_PAIRS)));
             // ... and two rows per wave (k_stream_pairs): twelve waves that all work in every iteration, 10 steps per launch by default (up
             // to SP_MAX_S), a launch that costs in proportion to its steps -- so no tile-kernel tails
-            c->stream_pairs = c->stream_walls && (p->flags & LBM_FLAG_STREAM_PAIRS);
+            c->stream_pairs = c->stream_walls && !slab && (p->flags & LBM_FLAG_STREAM_PAIRS);
             if (c->stream_pairs) {
                 c->tb_steps = p->tb_steps ? p->tb_steps : 10;
                 c->tail_tiles = false;
@@ -340,9 +362,10 @@ int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
     if (c->stream) {
         const StreamPlan pl = plan_stream(c, S);
         wgs = (long long)pl.nstrips * pl.nsegy;
-        const long long rows = c->geo.ny - (c->stream_walls ? 0 : 2 * c->tb_f);
-        // (with the walls inside the first / last segment has no lead rows beyond the wall)
-        wave_updates = (long long)pl.nstrips * (rows + ((long long)pl.nsegy * 2 - (c->stream_walls ? 2 : 0)) * (S - 1)) * S;
+        const int nbr = (has_neighbour(c, LBM_SIDE_LOW) ? 1 : 0) + (has_neighbour(c, LBM_SIDE_HIGH) ? 1 : 0);
+        const long long rows = c->geo.ny - (c->stream_walls ? nbr * c->tb_f : 2 * c->tb_f);
+        // (with the walls inside a segment that starts / ends at a wall has no lead rows beyond it; a slab's bulk launch only)
+        wave_updates = (long long)pl.nstrips * (rows + ((long long)pl.nsegy * 2 - (c->stream_walls ? 2 - nbr : 0)) * (S - 1)) * S;
     } else if (c->use_tb && S >= 3) {
         const int F = c->tb_f, RV = (S - 1 + V - 1) / V, TX = (16 - 2 * RV) * V, TY = 32 - 2 * (S - 1);
         const long long ntx = (c->geo.nx - 2 * F + TX - 1) / TX, nty = (c->geo.ny - 2 * F + TY - 1) / TY;
@@ -356,7 +379,7 @@ int lbm_describe(const lbm_ctx* c, char* buf, size_t len) {
     const int n = std::snprintf(buf, len, "kernel=%s steps_per_launch=%d frame=%d stream=%d vec=%d nt=%d deep_halo=%d frame_fused=%d lazy_lag=%d "
                                 "layout=%s workgroups=%lld wave_updates=%lld cells_per_lane=%d slab=%d frame_beside=%d frame_seg=%d "
                                 "lattices=%d lattice_bytes=%lld",
-                                kern, S, c->use_tb ? (c->stream_walls ? 0 : c->tb_f) : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
+                                kern, S, c->use_tb ? (c->stream_walls && !is_slab(c) ? 0 : c->tb_f) : 0, c->stream ? 1 : 0, c->use_vec ? 1 : 0, c->use_nt ? 1 : 0, c->deep_halo ? 1 : 0,
                                 c->frame_fused ? 1 : 0, c->lazy_lag ? 1 : 0, c->geo.row != c->geo.pitch ? "rows" : "planes", wgs, wave_updates, V,
                                 is_slab(c) ? 1 : 0, c->frame_beside ? 1 : 0, c->frame_seg, nlat, (long long)c->lat_bytes);
     return n < 0 ? LBM_ERR_INVALID : (n >= (int)len ? (int)len - 1 : n);

@@ -234,7 +234,7 @@ __device__ __forceinline__ void build_in(typename VecT<R, V>::type (&in)[Q], typ
 // cell is x = nx - 1 holds the right wall, row 0 / ny - 1 are wall rows; stores go to the lane's cells in [own_lo, own_hi).
 // Without WALLS (k_stream: the wall-free interior of a lattice with a frame, the rows between slabs) own_lo / own_hi are unused
 // and the stored columns are [xs + R, xs + 64 V - R) below xe.
-template <typename R, int COLL, bool TURB, bool WALLS = false>
+template <typename R, int COLL, bool TURB, bool WALLS = false, bool SLAB = false>
 __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __restrict__ dst, const Geo& geo, const Relax<R>& w, R* __restrict__ lds,
                                                int S, int xs, int ya, int yb, int xe, int own_lo = 0, int own_hi = 0) {
     constexpr int V = 16 / (int)sizeof(R), ROW = 64 * V;        // cells of a wave-row
@@ -247,8 +247,14 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
     const int q = ((wv & 7) << 1) | (wv >> 3);
     const int RV = stream_rim(S, V) / V;                          // rim, in vector cells
     // rows that go through the pipeline: the segment's own and S - 1 lead rows on each side (WALLS: none beyond a wall row)
-    const int y_first = WALLS ? max(ya - (S - 1), 0) : ya - (S - 1);
-    const int y_end = WALLS ? min(yb + (S - 1), geo.ny) : yb + (S - 1);
+    // (SLAB: its first / last row is a wall row only where the slab holds the lid / the bottom wall; towards a neighbour the lead rows
+    // are the neighbour's rows of the deep halo in the ghost rows, as in k_stream's edge segments.  A kernel of its own, k_stream_walls_slab:
+    // the lone lattice's sits exactly at the scalar AND the vector register limit, and the two scalars below tip its fast operator into
+    // 14 spilled registers -- 424 -> 404 GLUPS)
+    const bool wall_lo = WALLS && (!SLAB || geo.y0 == 0), wall_hi = WALLS && (!SLAB || geo.y0 + geo.ny == geo.NY);
+    const int y_first = wall_lo ? max(ya - (S - 1), 0) : ya - (S - 1);
+    const int y_end = wall_hi ? min(yb + (S - 1), geo.ny) : yb + (S - 1);
+    const int y_lid = wall_lo ? 0 : -(1 << 30), y_bot = wall_hi ? geo.ny - 1 : -(1 << 30);   // the wall rows this lattice / slab holds
     const int nb = y_end - y_first;                               // blocks (rows)
     const int x0 = xs + lane * V;
     const bool lane_in = x0 < geo.nx;                             // (the last strip may reach beyond the lattice)
@@ -453,7 +459,7 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
     load_row(y_first + q, q < nb);
     for (int b = q; b < nb; b += ST_WAVES) {
         const int y = y_first + b;
-        if (WALLS && (y == 0 || y == geo.ny - 1)) block(b, std::true_type{});
+        if (WALLS && (SLAB ? (y == y_lid || y == y_bot) : (y == 0 || y == geo.ny - 1))) block(b, std::true_type{});
         else block(b, std::false_type{});
         done += ST_WAVES;
     }
@@ -519,6 +525,36 @@ __global__ __launch_bounds__(ST_NT) void k_stream_walls(const R* __restrict__ sr
     const int ya = sy * H, yb = min(geo.ny, ya + H);
     if (ya >= yb) return;
     stream_segment<R, COLL, TURB, true>(src, dst, geo, w, lds, S, xs, ya, yb, 0, own_lo, own_hi);
+}
+// ... and for a slab with the deep halo in its ghost rows (r03): the same strips; a unit is two launches (multi_step) -- the edge bands
+// (bands != 0: the F rows next to each interface, over the whole width, as segments of their own whose pipeline starts S - 1 rows inside
+// the neighbour's rows of the deep halo; lo / hi = e + 1: e rows of the neighbour's side are owned on top -- the lagged lattice; bit 0 =
+// the interface above row 0, bit 1 = the one below row ny - 1) and the rows [ybeg, yend) between them, segment j from ybeg + j H.
+template <typename R, int COLL, bool TURB>
+__global__ __launch_bounds__(ST_NT) void k_stream_walls_slab(const R* __restrict__ src, R* __restrict__ dst, Geo geo, Relax<R> w, int S, int nstrips, int H,
+                                                             int xcd_bands, int ybeg, int yend, int bands, int lo, int hi, int F) {
+    __shared__ __align__(16) R lds[ST_LDS_BYTES / sizeof(R)];
+    constexpr int V = 16 / (int)sizeof(R), W = 64 * V;
+    int b = blockIdx.x;
+    if (xcd_bands) {
+        const int per = (int)gridDim.x >> 3;
+        if (b < (per << 3)) b = (b & 7) * per + (b >> 3);
+    }
+    const int strip = b % nstrips, sy = b / nstrips;
+    const int R_ = stream_rim(S, V), TXu = W - 2 * R_;
+    const int xs = min(strip * TXu, max(geo.nx - W, 0));
+    const int own_lo = strip == 0 ? 0 : strip * TXu + R_;
+    const int own_hi = strip == nstrips - 1 ? geo.nx : (strip + 1) * TXu + R_;
+    int ya, yb;
+    if (bands) {
+        const bool top = (bands & 1) && sy == 0;
+        if (top) { ya = -(lo > 0 ? lo - 1 : 0); yb = F; }
+        else { ya = geo.ny - F; yb = geo.ny + (hi > 0 ? hi - 1 : 0); }
+    } else {
+        ya = ybeg + sy * H; yb = min(yend, ya + H);
+    }
+    if (ya >= yb) return;
+    stream_segment<R, COLL, TURB, true, true>(src, dst, geo, w, lds, S, xs, ya, yb, 0, own_lo, own_hi);
 }
 // strips of k_stream_walls for a lattice nx wide (host and device agree through this one function)
 __host__ __device__ constexpr int stream_walls_strips(int nx, int S, int V) {
@@ -827,6 +863,25 @@ LBM_STREAMW_ALL(float)
 #endif
 #if !defined(LBM_STREAM_ONLY_F32) && !defined(LBM_STREAMW_SKIP)
 LBM_STREAMW_ALL(double)
+#endif
+
+// ... the slab variant of the same: lbm_streams_f32.hip / lbm_streams_f64.hip
+#ifndef LBM_STREAMS_EXTERN
+#define LBM_STREAMS_EXTERN extern
+#endif
+#define LBM_STREAMS_ONE(R, COLL, TURB)                                                                                    \
+    LBM_STREAMS_EXTERN template __global__ void k_stream_walls_slab<R, COLL, TURB>(const R* __restrict__, R* __restrict__, Geo, Relax<R>, int, int, int, \
+                                                                                   int, int, int, int, int, int, int);
+#define LBM_STREAMS_ALL(R)                                                                                                \
+    LBM_STREAMS_ONE(R, C_SRT, false) LBM_STREAMS_ONE(R, C_TRT, false) LBM_STREAMS_ONE(R, C_MRT, false)                      \
+    LBM_STREAMS_ONE(R, C_MRT_FAST, false) LBM_STREAMS_ONE(R, C_SRT_FAST, false) LBM_STREAMS_ONE(R, C_TRT_FAST, false)       \
+    LBM_STREAMS_ONE(R, C_SRT, true) LBM_STREAMS_ONE(R, C_TRT, true) LBM_STREAMS_ONE(R, C_MRT, true)                         \
+    LBM_STREAMS_ONE(R, C_MRT_FAST, true) LBM_STREAMS_ONE(R, C_SRT_FAST, true) LBM_STREAMS_ONE(R, C_TRT_FAST, true)
+#if !defined(LBM_STREAM_ONLY_F64) && !defined(LBM_STREAMS_SKIP)
+LBM_STREAMS_ALL(float)
+#endif
+#if !defined(LBM_STREAM_ONLY_F32) && !defined(LBM_STREAMS_SKIP)
+LBM_STREAMS_ALL(double)
 #endif
 
 #ifndef LBM_STREAM_EXTERN

@@ -3,4 +3,5 @@
 #define LBM_STREAM_ONLY_F32
 #define LBM_STREAM_SKIP
 #define LBM_STREAMW_SKIP
+#define LBM_STREAMS_SKIP
 #include "lbm_stream.hpp"

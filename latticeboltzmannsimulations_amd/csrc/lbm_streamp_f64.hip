@@ -3,4 +3,5 @@
 #define LBM_STREAM_ONLY_F64
 #define LBM_STREAM_SKIP
 #define LBM_STREAMW_SKIP
+#define LBM_STREAMS_SKIP
 #include "lbm_stream.hpp"

@@ -1140,7 +1140,7 @@ def test_streaming_slab_units_at_benchmark_sizes_in_loopback(nx, rows, dtype):
     fin0 = _smooth_state(nx, 3 * rows, dtype)
     a.set_state(fin0); b.set_state(fin0)
     del fin0
-    assert a.describe()["kernel"] == "k_stream" and a.describe()["slab"] == 1
+    assert a.describe()["kernel"] == "k_stream_walls" and a.describe()["slab"] == 1
     for steps in (1, 64, 27, 81):
         a.step(steps); b.step(steps)
     assert a.next_unit(100) == 8 and b.next_unit(100) == 1
