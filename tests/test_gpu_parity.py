@@ -1214,7 +1214,7 @@ SLAB_CASES = [(np.float32, "MRT", 0, "strict"), (np.float32, "MRT", 0, "fast"), 
               (np.float64, "MRT", 0, "strict"), (np.float64, "MRT", 0, "fast")]
 
 
-@pytest.mark.parametrize("kernel", ["tb", "stream"])
+@pytest.mark.parametrize("kernel", ["tb", "stream", "stream_frame"])
 @pytest.mark.parametrize("nslabs", [2, 3, 8])
 @pytest.mark.parametrize("dtype,coll,turb,arith", SLAB_CASES)
 def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, arith, nslabs, kernel):
@@ -1222,7 +1222,9 @@ def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, 
     last slab (bottom wall): launch units of S steps, each preceded by the exchange of the S complete rows next to every
     interface (lbm_halo_export_rows -> lbm_halo_import_rows) and run by lbm_step_unit = lbm_step's own multi-step launch
     sequence (frame passes that recompute a shrinking band of the neighbour's rows + tile kernel, two streams; kernel = stream:
-    edge launch -- column strips + the interface rows as segments of the streaming kernel -- + bulk launch).  Uneven slab
+    edge launch + bulk launch -- "stream": the walls inside, k_stream_walls_slab, the edge launch is the interface bands alone (the
+    library's choice where the operator variant does not spill; forced here); "stream_frame": k_stream, edge launch = column strips +
+    the interface rows as segments of the streaming kernel).  Uneven slab
     heights, several calls whose lengths leave every remainder, fields read after every call (one-step lag recomputed from
     the deep halo on slabs).  Expected: the undivided lattice, bit for bit (and the C oracle for strict arithmetic)."""
     nx, ny = 512, 75 * 8 + 5
@@ -1231,7 +1233,11 @@ def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, 
     mr = min(n for _, n in parts)
     o = CavityOracleC(nx, ny, 1000.0, semantics="mrt_gpu", collision=coll, dtype=dtype, turb=turb) if arith == "strict" else None
     one = CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel="vec")
-    slabs = [CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel=kernel, rows=r, min_rows=mr) for r in parts]
+    tuning = {} if kernel == "tb" else dict(stream_walls=kernel == "stream")
+    slabs = [CavitySolver(nx, ny, 1000.0, RT=coll, dtype=dtype, turb=turb, arith=arith, kernel=kernel.split("_")[0], rows=r, min_rows=mr, tuning=tuning)
+             for r in parts]
+    if kernel != "tb":
+        assert {sl.describe()["kernel"] for sl in slabs} == {"k_stream_walls" if kernel == "stream" else "k_stream"}
     assert slabs[0].next_unit(1) == 1                                       # raw lattice: a single step first
     drv = LocalSlabs(slabs)
     units = set()
@@ -1246,7 +1252,7 @@ def test_slabs_through_multi_step_units_equal_single_lattice(dtype, coll, turb, 
         if o is not None:
             o.step(n)
             assert np.array_equal(fin, o.fin) and np.array_equal(u, o.u) and np.array_equal(rho, o.rho), n
-    assert max(units) >= (8 if kernel == "stream" else 3), units            # the multi-step path really ran
+    assert max(units) >= (8 if kernel != "tb" else 3), units                # the multi-step path really ran
     means = [sl.mean_u() * sl.ny_local for sl in slabs]
     assert abs(sum(means) / ny - one.mean_u()) < 1e-12
     for sl in slabs:
