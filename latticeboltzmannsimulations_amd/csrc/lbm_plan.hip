@@ -28,7 +28,7 @@ StreamPlan plan_stream_on(const lbm_ctx* c, int S, int ncu, long long* cost_out)
     for (int n = 1; n <= 256 && n * 8 <= std::max(rows, 8); ++n) {
         const int H = (rows + n - 1) / n, nseg = (rows + H - 1) / H;
         const long long segs = (long long)best.nstrips * nseg, rounds = (segs + ncu - 1) / ncu;
-        long long iters = (H + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
+        long long iters = H + 2 * (S - 1) + ST_WAVES - 1;      // (block b starts in iteration b and takes 16: stream_segment)
         if (c->stream_pairs) {   // W waves, a pair of rows each: 2 W iterations per W pairs
             const long long Wv = pairs_waves(S), np = (H + 2 * (S - 1) + 1) / 2;
             iters = 2 * Wv * ((np + Wv - 1) / Wv) + 2 * Wv;
@@ -52,19 +52,21 @@ StreamPlan plan_stream(const lbm_ctx* c, int S) {
     const int nb = (has_neighbour(c, LBM_SIDE_LOW) ? 1 : 0) + (has_neighbour(c, LBM_SIDE_HIGH) ? 1 : 0), L = c->frame_seg;
     const long long n_edge = c->stream_walls ? (long long)nb * p0.nstrips     // (the walls inside: the interface bands alone)
                                              : (long long)nb * p0.nstrips + 2LL * ((c->geo.ny + L - 1) / L) + (2LL - nb) * ((c->geo.nx + L - 1) / L);
-    const long long edge_it = (c->tb_f + 2 * (S - 1) + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
+    const long long edge_it = c->tb_f + 2 * (S - 1) + ST_WAVES - 1;
     // (measured: a bulk launch longer than ~1.5 edge workgroups overlaps the frame variant's ~100 short edge workgroups well enough as
     // it is.  With the walls inside the edge launch is the 2 x nstrips band workgroups alone, each of which holds a CU -- all its LDS --
     // for edge_it iterations, and the bulk workgroups that find no CU start that much later: leaving them room pays up to a bulk launch
     // of ~3 edge workgroups -- 4096 x 512 fp32 slab in loopback 141 -> 177 GLUPS, 4096 x 1024 210 -> 244, 4096 x 2048 289 -> 274:
     // profiles/r03_logs/slab_walls.log)
-    if (c->stream_walls ? cost0 > 3 * edge_it : 2 * cost0 > 3 * edge_it) return p0;
+    if (c->stream_walls ? cost0 > 3 * edge_it : 4 * cost0 > 7 * edge_it) return p0;   // (the frame variant: segments of up to ~35 rows, as measured in r02)
     StreamPlan best = p0;
     long long best_cost = cost0 + edge_it * ((n_edge + c->ncu - 1) / c->ncu);
-    // (workgroups go to the eight XCDs in turn, whatever is free where: "room" is per XCD -- kernel trace of the 4096 x 1024 slab, 34 + 221
-    // workgroups on 256 CUs: XCD 0 is dealt 5 + 28 and its last bulk workgroup starts when an edge workgroup ends, 43 us late -- so the
-    // CUs left to the edge workgroups are counted in eighths, rounded up)
-    const long long xcd = c->stream_walls ? 8 : 1;
+    // (workgroups go to the eight XCDs in turn and, inside an XCD, to its four shader engines in turn, whatever is free where: "room" is
+    // per shader engine, 8 CUs.  Kernel trace of the 4096 x 1024 slab, 34 + 221 workgroups on 256 CUs: XCD 0 is dealt 5 + 28 and its last
+    // bulk workgroup starts when an edge workgroup ends, 43 us late; 34 + 204 -- 31 per XCD at most -- still waits, 34 + 187 does not
+    // (a sweep of the CUs left free: 40, 48 -> 209 GLUPS, 56, 64 -> 236, 72 -> 222: profiles/r03_logs/slab_walls.log).  So the CUs left
+    // to the edge workgroups are counted in units of 32, rounded up.)
+    const long long xcd = c->stream_walls ? 32 : 1;
     auto per_xcd = [&](long long n) { return (n + xcd - 1) / xcd * xcd; };
     if (c->stream_walls && per_xcd((long long)p0.nstrips * p0.nsegy) + per_xcd(n_edge) <= c->ncu) best_cost = std::max(cost0, edge_it);   // (room for both)
     // (div > 1: the edge workgroups in several rounds on fewer CUs -- the frame variant's many short ones; the band workgroups of the
@@ -229,8 +231,18 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
         // and 512 rows.  Lattices
         // narrower than 2048 (few strips, not measured) keep the earlier 3072^2 rule.
         const long long cells_plan = (long long)p->nx * ny_plan;
-        const bool stream_pays = p->nx >= 2048 ? (slab ? cells_plan >= (1LL << 20) && ny_plan >= 512 : cells_plan >= ((c->es == 8 ? 4LL : 8LL) << 20))
-                                               : cells_plan >= 3072LL * 3072;
+        // r03 (profiles/r03_logs/auto_sweep.log): a lone lattice whose operator variant takes the walls inside (no frame workgroups ahead of the
+        // streaming ones; waves that end with their last block) pays earlier -- stream / tile, fast MRT: fp32 4096 x 512 238 / 224, 2048^2 303 /
+        // 263, 4096 x 1024 317 / 257 but 1536^2 241 / 248, 2048 x 1024 228 / 237 -> wide lattices from 2 Mi cells, the others from 4 Mi at
+        // 2048 columns; fp64 1024^2 112 / 101 (strict 84.5 / 82), 2048 x 512 109 / 100, 1280^2 134 / 113, 1536^2 151 / 116 but 768^2 80 / 87 -> from
+        // 1 Mi cells and 1024 columns
+        const bool walls_variant = c->batch == 1 && !slab && p->semantics == LBM_SEM_MRT_GPU && !p->turb && !(p->flags & LBM_FLAG_NO_STREAM_WALLS) &&
+                                   (p->collision == LBM_MRT || (p->collision == LBM_SRT && c->es == 8));
+        const bool walls_pays = walls_variant && (c->es == 8 ? p->nx >= 1024 && cells_plan >= (1LL << 20)
+                                                             : (p->nx >= 4096 && cells_plan >= (2LL << 20)) || (p->nx >= 2048 && cells_plan >= (4LL << 20)));
+        const bool stream_pays = walls_pays ||
+                                 (p->nx >= 2048 ? (slab ? cells_plan >= (1LL << 20) && ny_plan >= 512 : cells_plan >= ((c->es == 8 ? 4LL : 8LL) << 20))
+                                                : cells_plan >= 3072LL * 3072);
         c->stream = can_stream && (p->kernel == LBM_KERNEL_STREAM || (p->kernel == LBM_KERNEL_AUTO && stream_pays));
         if (c->stream) {
             c->use_tb = true;

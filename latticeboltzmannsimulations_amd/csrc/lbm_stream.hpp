@@ -453,17 +453,17 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
     // ones, then idle ones up to the common total; every iteration ends with the workgroup barrier (one per iteration for every
     // wave).  Written as loops over blocks and levels -- not as one loop over iterations with a test -- so that the prefetched
     // row (in[]) is live only between two blocks and the carried planes (outv[0], [1], [3]) only inside a block.
-    const int jtot = (nb + ST_WAVES - 1) / ST_WAVES * ST_WAVES + ST_WAVES;
-    int done = q;
+    // After its last block a wave simply ends: s_barrier counts the waves of the workgroup that are still alive, so the others go on
+    // without it (its posts stay in LDS, which the workgroup keeps to its end).  The workgroup is over nb + 15 iterations after it
+    // began -- r02 / early r03 had every wave sit out a common total of ceil(nb / 16) 16 + 16: nothing for a tall segment, 48 -> 37
+    // iterations for a slab's edge band, 80 -> 66 for the 37-row segments of a 1024-row lattice.
     for (int i = 0; i < q; ++i) lds_barrier();
     load_row(y_first + q, q < nb);
     for (int b = q; b < nb; b += ST_WAVES) {
         const int y = y_first + b;
         if (WALLS && (SLAB ? (y == y_lid || y == y_bot) : (y == 0 || y == geo.ny - 1))) block(b, std::true_type{});
         else block(b, std::false_type{});
-        done += ST_WAVES;
     }
-    for (; done < jtot; ++done) lds_barrier();
 }
 
 // grid: [nframe frame workgroups (a lone lattice)] + nstrips * nsegy segments.  S <= ST_MAX_S steps; F = frame width (>= S, and >= S + 1

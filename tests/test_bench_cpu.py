@@ -107,19 +107,19 @@ def test_every_rank_of_the_multi_gpu_bench_plans_the_same_protocol():
     assert any(without[0][k] != without[1][k] for k in bench.PROTOCOL_KEYS), "the example no longer straddles a threshold: pick another"
 
 
-def test_a_short_slab_leaves_cus_to_its_band_workgroups_per_xcd():
+def test_a_short_slab_leaves_cus_to_its_band_workgroups_per_shader_engine():
     """A slab's unit is an edge launch (the interface bands: 2 x nstrips workgroups, each holding a CU) and a bulk launch.  Workgroups are
-    dealt to the eight XCDs in turn, so a one-round bulk launch must leave the band workgroups room in every XCD -- ceil(bands / 8) +
-    ceil(bulk / 8) <= 32 -- up to a bulk launch of three band workgroups' length (lbm_plan.hip, plan_stream; profiles/r03_logs/slab_walls.log);
-    a long or multi-round bulk launch takes the whole device."""
+    dealt to the eight XCDs and their four shader engines in turn, so a one-round bulk launch must leave the band workgroups room in
+    every shader engine -- ceil(bands / 32) + ceil(bulk / 32) <= 8 -- up to a bulk launch of three band workgroups' length (lbm_plan.hip,
+    plan_stream; profiles/r03_logs/slab_walls.log); a long or multi-round bulk launch takes the whole device."""
     from latticeboltzmannsimulations_amd import launch_plan
     for rows, reserve in ((512, True), (1024, True), (2048, False)):
         d = launch_plan(4096, 3 * rows, 1000.0, dtype=np.float32, arith="fast", rows=(rows, rows), steps=16)
         assert d["kernel"] == "k_stream_walls" and d["slab"] == 1 and d["frame"] == 8, d
         bands = 2 * 17                                                # two interfaces x 17 strips of 240 columns
-        fits = -(-bands // 8) + -(-d["workgroups"] // 8) <= 32
+        fits = -(-bands // 32) + -(-d["workgroups"] // 32) <= 8
         assert fits == reserve, (rows, d["workgroups"])
     first = launch_plan(4096, 3072, 1000.0, dtype=np.float32, arith="fast", rows=(0, 1024), steps=16)        # one interface: 17 band workgroups
-    assert -(-17 // 8) + -(-first["workgroups"] // 8) <= 32 and first["workgroups"] > 187, first
+    assert -(-17 // 32) + -(-first["workgroups"] // 32) <= 8 and first["workgroups"] > 187, first
     wide = launch_plan(16384, 3 * 2048, 1000.0, dtype=np.float32, arith="fast", rows=(2048, 2048), steps=16)  # several rounds: no reserve
     assert wide["workgroups"] > 256, wide
