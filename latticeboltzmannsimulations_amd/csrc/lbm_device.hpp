@@ -261,6 +261,60 @@ template <typename T>
 __device__ __forceinline__ T diag_flux(const T (&f)[Q]) {   // product = cx cy f_k + product, k = 0..8
     return -f[8] + (f[7] + (-f[6] + f[5]));
 }
+// Equilibrium + collision of a cell (or of two packed cells) from its macroscopic state, as every step kernel calls it; q2 (TURB only):
+// sum_k cx cy feq_k of THIS step, the closure's history (K_QEQ).  The strict operators and the factored MRT one: equ() -> collide() ->
+// diag_flux(), exactly the sequence the kernels spelled out before.  C_SRT_FAST / C_TRT_FAST (r03): the same operators with the
+// equilibrium never formed -- feq_k = rho t_k (B + 4.5 cu^2 +- 3 cu), B = 1 - 1.5 u^2, shares everything but the sign of the odd part
+// between the two directions of a pair, so
+//   SRT  f*_k = (1 - w) f_k + (w rho t_k) (E_k +- O_k),                      E = B + 4.5 cu^2, O = 3 cu
+//   TRT  f*_a/b = f_a/b - P -+ M,  P = w+ ((f_a + f_b) / 2 - rho t E),  M = w- ((f_a - f_b) / 2 - rho t O)
+// with fused multiply-adds: ~50 / ~65 operations per cell after the moments instead of ~105 / ~140, and sum_k cx cy feq_k = rho ux uy
+// exactly.  Same operator, other rounding: NOT the reference's operation order (tolerances: tests/test_gpu_parity.py::test_fast_arithmetic_*);
+// one spelling for every kernel, so a lattice gives the same bits however it is cut.
+template <typename T, int COLL, bool TURB>
+__device__ __forceinline__ void equ_collide(const T (&g)[Q], T rho, T ux, T uy, const Relax<typename ScalarOf<T>::type>& w, T w_nu, T (&out)[Q], T& q2) {
+    typedef typename ScalarOf<T>::type R;
+    // (fp32 SRT with the closure keeps the unfused sequence: at the streaming kernels' 128 registers the fused one spills there -- 4096^2
+    // 256 -> 210 GLUPS, while fp64 gains, 108 -> 134; without the closure it is what lets fp32 SRT take the walls kernel, 251 -> 414)
+    if constexpr ((COLL == C_SRT_FAST && !(TURB && sizeof(R) == 4)) || COLL == C_TRT_FAST) {
+        const T base = fma_(T((R)-1.5), fma_(uy, uy, ux * ux), T((R)1));
+        const T orho = w_nu * rho, c1 = (R)1 - w_nu;
+        const T r1 = (R)(1.0 / 9) * orho, r5 = (R)(1.0 / 36) * orho;
+        out[0] = fma_((R)(4.0 / 9) * orho, base, c1 * g[0]);
+        if constexpr (COLL == C_SRT_FAST) {
+            auto pair = [&](T cu, T rw, const T& ga, const T& gb, T& oa, T& ob) {
+                const T e = fma_((R)4.5 * cu, cu, base), o = (R)3 * cu;
+                oa = fma_(rw, e + o, c1 * ga);
+                ob = fma_(rw, e - o, c1 * gb);
+            };
+            pair(ux, r1, g[1], g[3], out[1], out[3]);
+            pair(uy, r1, g[2], g[4], out[2], out[4]);
+            pair(ux + uy, r5, g[5], g[7], out[5], out[7]);
+            pair(ux - uy, r5, g[8], g[6], out[8], out[6]);
+        } else {
+            const T mrho = w.w_m * rho, hp = (R)0.5 * w_nu;
+            const T m1 = (R)(1.0 / 9) * mrho, m5 = (R)(1.0 / 36) * mrho;
+            const R hm = (R)0.5 * w.w_m;
+            auto pair = [&](T cu, T rp, T rm, const T& ga, const T& gb, T& oa, T& ob) {
+                const T e = fma_((R)4.5 * cu, cu, base), o = (R)3 * cu;
+                const T P = fma_(-rp, e, hp * (ga + gb)), M = fma_(-rm, o, hm * (ga - gb));
+                oa = (ga - P) - M;
+                ob = (gb - P) + M;
+            };
+            pair(ux, r1, m1, g[1], g[3], out[1], out[3]);
+            pair(uy, r1, m1, g[2], g[4], out[2], out[4]);
+            pair(ux + uy, r5, m5, g[5], g[7], out[5], out[7]);
+            pair(ux - uy, r5, m5, g[8], g[6], out[8], out[6]);
+        }
+        if (TURB) q2 = rho * (ux * uy);
+    } else {
+        T fe[Q];
+        if (!coll_is_mrt(COLL) || TURB) equ<T>(rho, ux, uy, fe);     // (the plain MRT operator needs neither u nor feq: MRT_GPU.py:633-648)
+        collide<T, COLL>(g, rho, fe, w, w_nu, out);
+        if (TURB) q2 = diag_flux<T>(fe);
+    }
+}
+
 __device__ __forceinline__ float real_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double real_abs(double x) { return fabs(x); }
 __device__ __forceinline__ f32x2 real_abs(f32x2 x) { return f32x2{fabsf(x.x), fabsf(x.y)}; }
@@ -395,17 +449,16 @@ __device__ __forceinline__ void update_cell_a(const R* __restrict__ src, const A
         for (int k = 1; k < Q; ++k)
             if (!in_window<SEM>(k, x, gy, X, Y)) dst[k * ad.plane + ad.at(x - cxk(k), y + cyk(k))] = g[k];
     }
-    R rho, ux, uy, fe[Q], out[Q];
+    R rho, ux, uy, out[Q], q2 = (R)0;
     const auto me = ad.at(x, y);
     const auto me_s = as.at(x, y);
     const Relax<R>& w = w0;
     R w_nu = w0.w_nu;
     if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, src[K_QEQ * as.plane + me_s], src[K_RHO * as.plane + me_s], w0.w_nu);
     macros<R, coll_is_fast(COLL)>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
-    equ<R>(rho, ux, uy, fe);
-    collide<R, COLL>(g, rho, fe, w, w_nu, out);
+    equ_collide<R, COLL, TURB>(g, rho, ux, uy, w, w_nu, out, q2);
     if (TURB) {
-        dst[K_QEQ * ad.plane + me] = diag_flux<R>(fe);
+        dst[K_QEQ * ad.plane + me] = q2;
         dst[K_RHO * ad.plane + me] = rho;
     }
     if (!near_edge) {
@@ -481,7 +534,7 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
 #pragma unroll
     for (int c = 0; c < V; ++c) {
         const int x = x0 + c;
-        R g[Q], out[Q], fe[Q];
+        R g[Q], out[Q], q2 = (R)0;
 #pragma unroll
         for (int k = 0; k < Q; ++k) g[k] = in[k][c];
         const bool left = (c == 0) && (x == 0), right = (c == V - 1) && (x == X - 1);
@@ -492,16 +545,16 @@ __device__ __forceinline__ void update_vec(const R* __restrict__ src, R* __restr
         R w_nu = w0.w_nu;
         if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, hq[c], hr[c], w0.w_nu);
         R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
+        R ux = (R)0, uy = (R)0;
         if (!coll_is_mrt(COLL) || TURB) {   // the plain MRT operator needs neither u nor feq (MRT_GPU.py:633-648)
-            R ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
-            R uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
+            ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
+            uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
             if (left || right) { ux = (R)0; uy = (R)0; }
-            equ<R>(rho, ux, uy, fe);
         }
-        collide<R, COLL>(g, rho, fe, w0, w_nu, out);
+        equ_collide<R, COLL, TURB>(g, rho, ux, uy, w0, w_nu, out, q2);
 #pragma unroll
         for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
-        if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
+        if (TURB) { hq[c] = q2; hr[c] = rho; }
     }
 #pragma unroll
     for (int k = 0; k < Q; ++k) vstore<R, V, NT>(dst + k * geo.plane + me, outv[k]);
@@ -539,15 +592,15 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
         // fp32: two cells per operation (packed math), same lane-wise IEEE operations as the scalar form below
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            f32x2 g[Q], out[Q], fe[Q];
+            f32x2 g[Q], out[Q], q2 = f32x2(0.f);
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = p == 0 ? in[k].xy : in[k].zw;
             f32x2 w_nu = (f32x2)(w0.w_nu);
             if (TURB) w_nu = smagorinsky_omega<f32x2, coll_is_fast(COLL)>(g, p == 0 ? hq.xy : hq.zw, p == 0 ? hr.xy : hr.zw, w0.w_nu);
             f32x2 rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
             if (kind == 1) rho = ((g[0] + g[1]) + g[3]) + 2.f * ((g[2] + g[5]) + g[6]);
+            f32x2 ux = f32x2(0.f), uy = f32x2(0.f);
             if (!coll_is_mrt(COLL) || TURB) {
-                f32x2 ux, uy;
                 if (kind == 0) {
                     ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
                     uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
@@ -556,16 +609,14 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
                 } else {
                     ux = f32x2(kind == 1 ? w0.uLB : 0.f); uy = f32x2(0.f);
                 }
-                equ<f32x2>(rho, ux, uy, fe);
             }
-            collide<f32x2, COLL>(g, rho, fe, w0, w_nu, out);
+            equ_collide<f32x2, COLL, TURB>(g, rho, ux, uy, w0, w_nu, out, q2);
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
                 if (p == 0) outv[k].xy = out[k];
                 else outv[k].zw = out[k];
             }
             if (TURB) {
-                const f32x2 q2 = diag_flux<f32x2>(fe);
                 if (p == 0) { hq.xy = q2; hr.xy = rho; }
                 else { hq.zw = q2; hr.zw = rho; }
             }
@@ -576,15 +627,15 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
     } else {
 #pragma unroll
         for (int c = 0; c < V; ++c) {
-            R g[Q], out[Q], fe[Q];
+            R g[Q], out[Q], q2 = (R)0;
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = in[k][c];
             R w_nu = w0.w_nu;
             if (TURB) w_nu = smagorinsky_omega<R, coll_is_fast(COLL)>(g, hq[c], hr[c], w0.w_nu);
             R rho = ((((((((g[0] + g[1]) + g[2]) + g[3]) + g[4]) + g[5]) + g[6]) + g[7]) + g[8]);
             if (kind == 1) rho = ((g[0] + g[1]) + g[3]) + (R)2. * ((g[2] + g[5]) + g[6]);
+            R ux = (R)0, uy = (R)0;
             if (!coll_is_mrt(COLL) || TURB) {
-                R ux, uy;
                 if (kind == 0) {
                     ux = div_<coll_is_fast(COLL)>((((((g[1] - g[3]) + g[5]) - g[6]) - g[7]) + g[8]), rho);
                     uy = div_<coll_is_fast(COLL)>((((((g[2] - g[4]) + g[5]) + g[6]) - g[7]) - g[8]), rho);
@@ -592,12 +643,11 @@ __device__ __forceinline__ void collide_vec(const typename VecT<R, V>::type (&in
                 } else {
                     ux = kind == 1 ? w0.uLB : (R)0; uy = (R)0;
                 }
-                equ<R>(rho, ux, uy, fe);
             }
-            collide<R, COLL>(g, rho, fe, w0, w_nu, out);
+            equ_collide<R, COLL, TURB>(g, rho, ux, uy, w0, w_nu, out, q2);
 #pragma unroll
             for (int k = 0; k < Q; ++k) outv[k][c] = out[k];
-            if (TURB) { hq[c] = diag_flux<R>(fe); hr[c] = rho; }
+            if (TURB) { hq[c] = q2; hr[c] = rho; }
         }
     }
 }

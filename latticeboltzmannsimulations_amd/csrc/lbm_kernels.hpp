@@ -298,13 +298,12 @@ __global__ __launch_bounds__(BLK) void k_push_collide(const R* __restrict__ fin,
     const int x = blockIdx.x * BLK + threadIdx.x, y = blockIdx.y;
     if (x >= geo.nx) return;
     const int X = geo.nx, Y = geo.NY, gy = geo.y0 + y;
-    R g[Q], rho, ux, uy, fe[Q], out[Q];
+    R g[Q], rho, ux, uy, out[Q], q2;
     const long long me = geo.at(x, y);
 #pragma unroll
     for (int k = 0; k < Q; ++k) g[k] = fin[k * geo.plane + me];
     macros<R, coll_is_fast(COLL)>(g, x, gy, X, Y, w.uLB, rho, ux, uy);
-    equ<R>(rho, ux, uy, fe);
-    collide<R, COLL>(g, rho, fe, w, w.w_nu, out);
+    equ_collide<R, COLL, false>(g, rho, ux, uy, w, w.w_nu, out, q2);
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
         const int dx = x + cxk(k), dgy = gy - cyk(k);

@@ -237,7 +237,7 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
         // 2048 columns; fp64 1024^2 112 / 101 (strict 84.5 / 82), 2048 x 512 109 / 100, 1280^2 134 / 113, 1536^2 151 / 116 but 768^2 80 / 87 -> from
         // 1 Mi cells and 1024 columns
         const bool walls_variant = c->batch == 1 && !slab && p->semantics == LBM_SEM_MRT_GPU && !p->turb && !(p->flags & LBM_FLAG_NO_STREAM_WALLS) &&
-                                   (p->collision == LBM_MRT || (p->collision == LBM_SRT && c->es == 8));
+                                   (p->collision == LBM_MRT || p->collision == LBM_SRT);
         const bool walls_pays = walls_variant && (c->es == 8 ? p->nx >= 1024 && cells_plan >= (1LL << 20)
                                                              : (p->nx >= 4096 && cells_plan >= (2LL << 20)) || (p->nx >= 2048 && cells_plan >= (4LL << 20)));
         const bool stream_pays = walls_pays ||
@@ -276,7 +276,7 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
             // r03, second half: a slab too (its deep halo is complete rows of the same lattice format, side-wall cells included): the edge
             // launch shrinks to the interface bands, the column strips and the lid / bottom row strip of the frame go
             const bool walls_ok = c->batch == 1 && p->semantics == LBM_SEM_MRT_GPU && (!slab || !(p->flags & LBM_FLAG_NO_DEEP_HALO));
-            bool walls_pay = !p->turb && (p->collision == LBM_MRT || (p->collision == LBM_SRT && c->es == 8));
+            bool walls_pay = !p->turb && (p->collision == LBM_MRT || p->collision == LBM_SRT);
             if (walls_ok && walls_pay && device && !(p->flags & (LBM_FLAG_STREAM_WALLS | LBM_FLAG_STREAM_PAIRS))) {
                 dispatch(c->p, [&](auto v) {
                     using VT = decltype(v);
@@ -285,7 +285,8 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
                         hipFuncAttributes at;
                         const void* kern = slab ? reinterpret_cast<const void*>(&k_stream_walls_slab<R, VT::COLL, VT::TURB>)
                                                 : reinterpret_cast<const void*>(&k_stream_walls<R, VT::COLL, VT::TURB>);
-                        if (hipFuncGetAttributes(&at, kern) != hipSuccess || at.localSizeBytes > 64)
+                        // (SRT: ~25 registers parked per block, outside the level loop, 96 - 120 B; 412 GLUPS fast all the same)
+                        if (hipFuncGetAttributes(&at, kern) != hipSuccess || at.localSizeBytes > (p->collision == LBM_SRT ? 128u : 64u))
                             walls_pay = false;
                     }
                 });
