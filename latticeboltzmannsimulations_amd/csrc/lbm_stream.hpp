@@ -411,7 +411,7 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
                 lds_barrier();
             }
         }
-        {   // level S reached: prefetch this wave's next block (first: nothing it waits for is behind the stores), then store
+        {   // level S reached: store the row, then -- in the wave's idle iteration -- prefetch its next block
             const T hq_done = hq, hr_done = hr;      // (the prefetch overwrites the history registers)
             T rw_done = T{};
             R kl_done = (R)0, kr_done = (R)0;
@@ -420,9 +420,6 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
                 kl_done = st[ROW + lane];
                 kr_done = st[2 * ROW + lane];
             }
-            // (WALLS: store first -- with outv still live the prefetch would not fit the registers, and the compiler spills a register it has
-            // just loaded, i.e. waits for HBM right here; the loads then queue behind nine stores, which costs nothing measurable)
-            if (!WALLS) load_row(y_first + b + ST_WAVES, b + ST_WAVES < nb);
             if (lane_out && y >= ya && y < yb) {
 #pragma unroll
                 for (int k = 0; k < Q; ++k) vstore<R, V, false>(const_cast<R*>(cell(row_base(dst, k, y), 0)), outv[k]);
@@ -441,8 +438,15 @@ __device__ __forceinline__ void stream_segment(const R* __restrict__ src, R* __r
                     }
                 }
             }
-            if (WALLS) load_row(y_first + b + ST_WAVES, b + ST_WAVES < nb);
-            if (S > 1) { lds_barrier(); lds_barrier(); }
+            // The prefetch of this wave's next block goes into its IDLE iteration -- behind the barrier that ends the working one: the
+            // eighteen address computations and loads no longer lengthen the iteration every other wave waits for (each iteration has one
+            // wave that finishes a block), and one iteration still lies between them and the block's first update (r03: 4096^2 fp32 fast
+            // 419 -> 445 GLUPS, strict 288 -> 302, fp64 186.5 -> 198 / 129 -> 136; the frame variant k_stream, which had the prefetch AHEAD of
+            // the stores: MRT 365 -> 392, TRT 354 -> 368, SRT + closure 259 -> 274; the stores moved to the idle iteration as well: 425 -- they
+            // are what the loads queue behind: profiles/r03_logs/whatif.log)
+            if (S > 1) lds_barrier();
+            load_row(y_first + b + ST_WAVES, b + ST_WAVES < nb);
+            if (S > 1) lds_barrier();
         }
         for (int i = 2 * S; i < ST_WAVES; ++i) lds_barrier();
     };
