@@ -302,6 +302,9 @@ lbm_ctx* plan_ctx(const lbm_params* p, bool device, std::string& err_out) {
             } else if (c->tb_steps > ST_MAX_S) {
                 return (delete c, bail("tb_steps " + std::to_string(ST_MAX_S + 1) + " .. " + std::to_string(SP_MAX_S) + " need the streaming kernel with two rows per wave (a lone lattice, MRT_GPU semantics)"));
             }
+            // (with the walls inside the tails stay on the streaming kernel: the tile kernel's four steps are no faster any more -- 247 against 256
+            // GLUPS fast, 223 / 225 strict -- and the change of kernel inside a call costs: the driver's 20 steps, repeated, 337 -> 371 GLUPS)
+            if (c->stream_walls) c->tail_tiles = false;
             if (slab || c->stream_walls) c->frame_beside = false;   // (a slab's frame is its edge launch, multi_step; no frame at all with the walls inside)
             else if (p->flags & LBM_FLAG_FRAME_BESIDE_ON) c->frame_beside = true;
             else if (!(p->flags & LBM_FLAG_FRAME_BESIDE_OFF) && c->batch == 1 && c->es == 8) {
