@@ -56,7 +56,7 @@ StreamPlan plan_stream(const lbm_ctx* c, int S) {
     // (measured: a bulk launch longer than ~1.5 edge workgroups overlaps the frame variant's ~100 short edge workgroups well enough as
     // it is.  With the walls inside the edge launch is the 2 x nstrips band workgroups alone, each of which holds a CU -- all its LDS --
     // for edge_it iterations, and the bulk workgroups that find no CU start that much later: leaving them room pays up to a bulk launch
-    // of ~3 edge workgroups -- 4096 x 512 fp32 slab in loopback 141 -> 177 GLUPS, 4096 x 1024 210 -> 244, 4096 x 2048 289 -> 274:
+    // of ~3 edge workgroups -- 4096 x 512 fp32 slab in loopback 141 -> 186 GLUPS, 4096 x 1024 210 -> 245, 4096 x 2048 289 -> 274:
     // profiles/r03_logs/slab_walls.log)
     if (c->stream_walls ? cost0 > 3 * edge_it : 4 * cost0 > 7 * edge_it) return p0;   // (the frame variant: segments of up to ~35 rows, as measured in r02)
     StreamPlan best = p0;
@@ -66,13 +66,13 @@ StreamPlan plan_stream(const lbm_ctx* c, int S) {
     // bulk workgroup starts when an edge workgroup ends, 43 us late; 34 + 204 -- 31 per XCD at most -- still waits, 34 + 187 does not
     // (a sweep of the CUs left free: 40, 48 -> 209 GLUPS, 56, 64 -> 236, 72 -> 222: profiles/r03_logs/slab_walls.log).  So the CUs left
     // to the edge workgroups are counted in units of 32, rounded up.)
-    const long long xcd = c->stream_walls ? 32 : 1;
-    auto per_xcd = [&](long long n) { return (n + xcd - 1) / xcd * xcd; };
-    if (c->stream_walls && per_xcd((long long)p0.nstrips * p0.nsegy) + per_xcd(n_edge) <= c->ncu) best_cost = std::max(cost0, edge_it);   // (room for both)
+    const long long grain = c->stream_walls ? 32 : 1;
+    auto in_grains = [&](long long n) { return (n + grain - 1) / grain * grain; };
+    if (c->stream_walls && in_grains((long long)p0.nstrips * p0.nsegy) + in_grains(n_edge) <= c->ncu) best_cost = std::max(cost0, edge_it);   // (room for both)
     // (div > 1: the edge workgroups in several rounds on fewer CUs -- the frame variant's many short ones; the band workgroups of the
     // walls variant are all dispatched at once, ahead of the bulk launch, and hold what they get)
     for (int div = 1; div <= (c->stream_walls ? 1 : 3); ++div) {
-        const long long r = per_xcd((n_edge + div - 1) / div);
+        const long long r = in_grains((n_edge + div - 1) / div);
         if (r < 1 || r > c->ncu / 2) continue;
         long long cb = 0;
         const StreamPlan p = plan_stream_on(c, S, c->ncu - (int)r, &cb);
