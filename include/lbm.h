@@ -65,10 +65,11 @@ enum { LBM_FLAG_NO_DEEP_HALO = 1,        /* between slabs: a one-row exchange af
        LBM_FLAG_NO_EDGE_FIRST = 4096,    /* streaming kernel between slabs: do not hold the bulk launch back behind the edge launch */
        LBM_FLAG_NO_EDGE_RESERVE = 8192,  /* ... and do not plan a one-round bulk launch on fewer CUs to leave some to the edge workgroups */
        LBM_FLAG_NO_XCD_BANDS = 16384,    /* streaming kernel: workgroup i takes segment i (default: every XCD a contiguous run of segments) */
-       LBM_FLAG_NO_TAIL_TILES = 32768,   /* streaming contexts: units of 3 .. 5 steps through the streaming kernel too (default: the tile kernel) */
-       LBM_FLAG_STREAM_WALLS = 65536,    /* kernel STREAM, lone lattice, MRT_GPU semantics: the cells next to the walls inside the streaming kernel */
-       LBM_FLAG_NO_STREAM_WALLS = 262144,/* (k_stream_walls: no frame), always / never (default: for the operator variants whose kernel needs no
-                                            scratch memory -- MRT and fp64 SRT without the closure; the others keep the frame of single-step passes) */
+       LBM_FLAG_NO_TAIL_TILES = 32768,   /* streaming contexts with a wall frame: units of 3 .. 5 steps through the streaming kernel too (default:
+                                            the tile kernel; with the walls inside the tails stay on the streaming kernel anyway) */
+       LBM_FLAG_STREAM_WALLS = 65536,    /* kernel STREAM, MRT_GPU semantics, a lone lattice or a slab with the deep halo: the cells next to the walls */
+       LBM_FLAG_NO_STREAM_WALLS = 262144,/* inside the streaming kernel (k_stream_walls / k_stream_walls_slab: no frame), always / never (default: for the
+                                            operator variants whose kernel keeps its level loop free of scratch traffic -- MRT, SRT, no closure) */
        LBM_FLAG_STREAM_PAIRS = 131072 }; /* ... the walls inside AND two rows per wave, twelve waves, at most 10 steps per launch (k_stream_pairs:
                                             an r03 experiment, no faster than k_stream_walls -- DESIGN 2.4; kept for A/B) */
 
