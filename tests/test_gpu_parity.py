@@ -604,12 +604,17 @@ def test_slab_restart_from_global_state():
                                                      (1000, 256, "SRT", np.float64, 0.05, "strict"), (1000, 256, "MRT", np.float32, 0.05, "fast"),
                                                      (100, 128, "MRT", np.float64, 0.03, "fast"),
                                                      # the streaming kernel (what the benchmark lattices run), eight steps per launch
-                                                     (1000, 256, "MRT", np.float32, 0.05, "fast:stream"), (100, 128, "MRT", np.float64, 0.03, "strict:stream")])
+                                                     (1000, 256, "MRT", np.float32, 0.05, "fast:stream"), (100, 128, "MRT", np.float64, 0.03, "strict:stream"),
+                                                     # the fused SRT / TRT fast operators (r03: the equilibrium is never formed, lbm_device.hpp equ_collide),
+                                                     # and SRT with the closure -- the reference script's default mode
+                                                     (1000, 256, "SRT", np.float32, 0.05, "fast:stream"), (1000, 256, "TRT", np.float32, 0.05, "fast:stream"),
+                                                     (1000, 256, "TRT", np.float64, 0.05, "fast"), (1000, 256, "SRT", np.float64, 0.06, "fast:auto:turb")])
 def test_converged_cavity_matches_ghia(Re, n, RT, dtype, tol, arith):
     """T7 (physics): run to the reference's convergence criterion (MRT_GPU.py:883-889) and compare the centrelines
     with Ghia et al. at the geometrically correct positions; global mass drift stays small."""
     arith, _, kernel = arith.partition(":")
-    with CavitySolver(n, n, float(Re), RT=RT, dtype=dtype, arith=arith, kernel=kernel or "auto") as s:
+    kernel, _, turb = kernel.partition(":")
+    with CavitySolver(n, n, float(Re), RT=RT, dtype=dtype, arith=arith, kernel=kernel or "auto", turb=1 if turb else 0) as s:
         prev, quiet = None, 0
         for _ in range(400):
             s.step(3000)
@@ -625,7 +630,9 @@ def test_converged_cavity_matches_ghia(Re, n, RT, dtype, tol, arith):
     assert ex < tol and ey < tol, (ex, ey, s.steps_done)
     # the reference's own metric (MRT_GPU.py:815-821) samples the column at approximate, reversed rows: indicative only
     assert ghia.r2_value(u, Re, 0.08) > 0.9
-    assert abs(fin.sum() - n * n) / (n * n) < 2e-2
+    # (fp32 means never settle to 1e-8: those runs last all 1.2 M steps, over which the wall rules have let 1.7 % (SRT) / 3.7 % (TRT; the
+    # strict operator the same: 3.70 against 3.77 %, tools/probes/trt_mass.py) of the mass in; MRT 0.2 %, the fp64 runs stop after ~340 k steps at 1.5 %)
+    assert abs(fin.sum() - n * n) / (n * n) < (5e-2 if RT == "TRT" and dtype == np.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("Re,n,dtype,arith,kernel,cap,tol", [
