@@ -211,10 +211,13 @@ lbm_ctx* lbm_create(const lbm_params* p, char* err, size_t errlen) {
         if (p->flags & LBM_FLAG_COMM_PRIORITY_OFF) hi = lo;   // A/B: same priority as the compute stream
         if ((e = hipStreamCreateWithPriority(&c->s_comm, hipStreamNonBlocking, hi)) != hipSuccess) return cleanup("hipStreamCreate");
     }
-    if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
+    // (the events between the two streams of this context order kernels of ONE device: no system-scope release with every record -- a
+    // slab's unit records two and waits for two; 4096 x 512 slab in loopback 189 -> 195 GLUPS, 4096 x 1024 246 -> 251)
+    constexpr unsigned LBM_EVENT_FENCE = hipEventDisableSystemFence;
+    if ((e = hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming | LBM_EVENT_FENCE)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
-    if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
-    if ((e = hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming)) != hipSuccess) return cleanup("hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming | LBM_EVENT_FENCE)) != hipSuccess) return cleanup("hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming | LBM_EVENT_FENCE)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t0)) != hipSuccess) return cleanup("hipEventCreate");
     if ((e = hipEventCreate(&c->ev_t1)) != hipSuccess) return cleanup("hipEventCreate");
     // the two lattices (+ ftemp of the push scheme); the scratch lattices of the frame passes come on first use (ensure_scratch)
