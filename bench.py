@@ -254,6 +254,9 @@ def main():
                      "--master-port 29500 bench.py --gpus %d ..." % (a.gpus, a.gpus))
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
+    # (multi-process GPU work on this platform: the host driver only supports dmabuf IPC -- without this RCCL's handle exchange fails with
+    # "hipIpcGetMemHandle: invalid argument"; the launcher's environment normally carries it already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch                      # plumbing: process group, barrier, device sync
     import torch.distributed as dist
     from latticeboltzmannsimulations_amd.slab import attach_rccl
