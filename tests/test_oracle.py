@@ -258,3 +258,25 @@ print("sanitized cases ok:", n)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized cases ok: 80" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_identities_the_fused_fast_operators_rest_on():
+    """lbm_device.hpp equ_collide (arith = fast, SRT / TRT / the closure of MRT): with the oracle's own equilibrium,
+    (a) sum_k cx cy feq_k = rho ux uy (the closure's history, MRT_GPU.py:368-387, in closed form);
+    (b) feq_a + feq_b = 2 rho t (B + 4.5 cu^2) and feq_a - feq_b = 2 rho t (3 cu) for the opposite directions a, b of a pair, B = 1 - 1.5 u^2
+        (what lets SRT / TRT relax a pair from one even and one odd part);
+    to rounding, on random macroscopic states of the cavity's range."""
+    from oracle.lbm_numpy import CX, CY, equ, weights
+    rng = np.random.default_rng(7)
+    rho = 1.0 + 0.05 * rng.standard_normal((64, 48))
+    ux, uy = 0.1 * rng.standard_normal((64, 48)), 0.1 * rng.standard_normal((64, 48))
+    t = weights(np.float64)
+    fe = equ(rho, ux, uy, t)
+    q = sum(int(CX[k]) * int(CY[k]) * fe[k] for k in range(9))
+    assert np.abs(q - rho * ux * uy).max() < 1e-15
+    base = 1.0 - 1.5 * (ux * ux + uy * uy)
+    for a, b in ((1, 3), (2, 4), (5, 7), (8, 6)):
+        assert (CX[a], CY[a]) == (-CX[b], -CY[b])
+        cu = int(CX[a]) * ux + int(CY[a]) * uy
+        assert np.abs((fe[a] + fe[b]) - 2 * rho * t[a] * (base + 4.5 * cu * cu)).max() < 1e-15
+        assert np.abs((fe[a] - fe[b]) - 2 * rho * t[a] * (3.0 * cu)).max() < 1e-15
