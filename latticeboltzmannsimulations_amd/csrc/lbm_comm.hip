@@ -174,7 +174,11 @@ int exchange_ready(lbm_ctx* c, int rows) {
     static const bool off = std::getenv("LBM_DEBUG_NO_EXCHANGE_READY") != nullptr;   // (debug builds: shows that the tests see the race)
     if (off) return LBM_OK;
 #endif
-    if (c->edge_rows < rows) HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+    if (c->edge_rows < rows) {
+        const int rc = flush_int(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
+    }
     return LBM_OK;
 }
 

@@ -82,6 +82,10 @@ struct lbm_ctx {
     int batch = 1;              // independent lattices per buffer (lbm_params.batch)
     long long bstride = 0;      // elements from one lattice of the batch to the next
     void* relax_dev = nullptr;  // batch > 1: Relax<real>[batch] on the device
+    // The units of a lone lattice that need no second stream (frame and tiles / the walls inside: ONE launch on s_compute) neither wait for
+    // ev_edges nor record ev_int -- two event operations per unit, 7 - 8 % of a launch-bound lattice's step (160^2: 3.51 -> 3.24 us).  Instead:
+    bool int_stale = false;      // s_compute has work that ev_int does not cover yet: flush_int() before s_comm is made to wait for ev_int
+    bool edges_pending = false;  // ev_edges was recorded (work on s_comm) and s_compute has not been made to wait for it since
     std::string err;
 };
 
@@ -121,6 +125,15 @@ inline int fail(lbm_ctx* c, int code, const std::string& msg) {
         if (r_ != ncclSuccess)                                                                         \
             return fail((c), LBM_ERR_COMM, std::string(#expr) + ": " + rccl().GetErrorString(r_));     \
     } while (0)
+
+// ev_int, recorded lazily (lbm_ctx::int_stale): whoever makes s_comm wait for ev_int calls this first
+inline int flush_int(lbm_ctx* c) {
+    if (c->int_stale) {
+        HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+        c->int_stale = false;
+    }
+    return LBM_OK;
+}
 
 template <typename R>
 Relax<R> relax_of(const lbm_params& p) {

@@ -292,11 +292,14 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
             if (rc == LBM_OK) rc = enqueue_exchange(c, a);
             if (rc) return rc;
         }
+        int rc = flush_int(c);
+        if (rc) return rc;
         HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
-        int rc = launch_rows(c, a, b, 0, ny - 1, 2, c->s_comm);
+        rc = launch_rows(c, a, b, 0, ny - 1, 2, c->s_comm);
         if (rc) return rc;
         HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
         HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
+        c->edges_pending = true;
         rc = launch_rows(c, a, b, 1, 1, ny - 2, c->s_compute);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
@@ -305,10 +308,13 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
         *comm_used = true;
         return LBM_OK;
     }
-    if (c->use_tb) HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // frame kernels of an earlier multi-step
+    if (c->edges_pending) {   // frame kernels of an earlier multi-step
+        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
+        c->edges_pending = false;
+    }
     int rc = launch_rows(c, a, b, 0, 1, ny, c->s_compute);
     if (rc) return rc;
-    if (c->use_tb) HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+    c->int_stale = true;
     finish_unit(c, 1);
     return LBM_OK;
 }
@@ -324,10 +330,13 @@ int single_step(lbm_ctx* c, bool* comm_used, bool rccl_x) {
 int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
     const bool slab = is_slab(c);
     if (!slab && ((c->stream_walls && S >= 2) || (S >= 3 && c->frame_fused && !(c->stream && c->frame_beside)))) {   // a lone lattice: frame and tiles in ONE launch, everything on the compute stream
-        HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // (frame launches of an earlier unit, if any)
+        if (c->edges_pending) {   // (frame launches of an earlier unit on the second stream, if any)
+            HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));
+            c->edges_pending = false;
+        }
         int rc = launch_deep(c, c->cur, c->cur ^ 1, c->s_compute, S, true);
         if (rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+        c->int_stale = true;      // (ev_int is recorded when something on s_comm is made to wait for it: flush_int)
         finish_unit(c, S);
         return LBM_OK;
     }
@@ -340,6 +349,8 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
         if (rc == LBM_OK) rc = deep ? enqueue_deep_exchange(c, a, S) : enqueue_exchange(c, a);
         if (rc) return rc;
     }
+    rc = flush_int(c);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamWaitEvent(c->s_comm, c->ev_int, 0));
     HIP_TRY(c, hipStreamWaitEvent(c->s_compute, c->ev_edges, 0));   // this unit's tile kernel needs the previous unit's frame
     int from = a;
@@ -398,9 +409,11 @@ int multi_step(lbm_ctx* c, bool* comm_used, int S, bool rccl_x) {
       }
     }
     HIP_TRY(c, hipEventRecord(c->ev_edges, c->s_comm));
+    c->edges_pending = true;
     rc = launch_deep(c, a, b, c->s_compute, S);
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_int, c->s_compute));
+    c->int_stale = false;
     finish_unit(c, S);
     c->edge_rows = c->tb_f;
     *comm_used = true;
